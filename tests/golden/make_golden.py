@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""Generate the golden parity fixtures by IMPORTING the reference's own modules.
+
+Runs only in the build container, where /root/reference exists; the reference
+never travels to the GPU box -- only the small .npz vectors written here do.
+
+    python tests/golden/make_golden.py [--only schedule,ops,fwd,loop,train]
+
+What is captured:
+  schedule.npz      six [T] fp32 tables of ForwardSampler for three (T, scale)
+  ops_c{3,4}.npz    per-module inputs/outputs of a narrow UNet (BASE_CH=8)
+  fwd.npz           full-width UNet outputs on the ATC / CR-120 / 2x grids
+  loop.npz          _generate_ddpm / _generate_ddim results with injected noise
+  train.npz         loss + per-tensor gradient norms of one training step
+
+Weights and inputs are NOT stored: both sides regenerate them bit-identically
+from the integer PRNG (crowdmod-ddpm-4d_amd/prng.py, spec.init_params).
+
+Import notes: models/backbones/* and models/diffusion/forward.py import with
+torch alone.  models/diffusion/ddpm.py (home of DDPM.step/_generate_ddpm) also
+imports logging/plot/metrics packages that are absent here (wandb,
+torchmetrics, skimage, imageio, easydict, torchvision); none of them is touched
+by the arithmetic of the path, so empty placeholder modules are registered for
+them before the import.  No reference file is modified or copied.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from crowdmod_ddpm_4d_amd import prng, spec  # noqa: E402
+
+SEED_W, SEED_X = 42, 7
+
+
+# --------------------------------------------------------------------------- #
+def _placeholders():
+    class AttrDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for k, v in dict(d or {}, **kw).items():
+                self[k] = v
+
+        def __setitem__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, AttrDict):
+                v = AttrDict(v)
+            super().__setitem__(k, v)
+
+        __setattr__ = __setitem__
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError as e:
+                raise AttributeError(k) from e
+
+        def update(self, d=None, **kw):
+            for k, v in dict(d or {}, **kw).items():
+                self[k] = v
+
+    for name in ("wandb", "torchmetrics", "skimage", "skimage.metrics", "imageio", "imageio.v2",
+                 "easydict", "torchvision"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchmetrics"].MeanMetric = type("MeanMetric", (), {})
+    sys.modules["skimage.metrics"].structural_similarity = None
+    sys.modules["skimage"].metrics = sys.modules["skimage.metrics"]
+    sys.modules["easydict"].EasyDict = AttrDict
+    return AttrDict
+
+
+def ref_unet(cfg: spec.UNetConfig, params):
+    from models.backbones.unet import UNet
+    net = UNet(cfg.input_channels, cfg.output_channels, cfg.num_res_blocks, cfg.base_channels,
+               list(cfg.base_channels_multiples), list(cfg.apply_attention), cfg.dropout_rate,
+               cfg.time_multiple, cfg.condition)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()}, strict=True)
+    return net.eval()
+
+
+def synth_inputs(B, C, H, W, P, F, tag):
+    past = prng.normal(SEED_X, f"past/{tag}", B * C * H * W * P).reshape(B, C, H, W, P)
+    fut = prng.normal(SEED_X, f"future/{tag}", B * C * H * W * F).reshape(B, C, H, W, F)
+    return past, fut
+
+
+# --------------------------------------------------------------------------- #
+def gen_schedule(out):
+    from models.diffusion.forward import ForwardSampler
+    d = {}
+    for T, scale in ((1000, 0.5), (50, 0.5), (1000, 1.0)):
+        fs = ForwardSampler(timesteps=T, scale=scale)
+        for name in ("beta", "alpha", "alpha_bar", "sqrt_alpha_bar", "one_by_sqrt_alpha",
+                     "sqrt_one_minus_alpha_bar"):
+            d[f"T{T}_s{scale}/{name}"] = getattr(fs, name).numpy()
+    # q-sample with injected noise: forward.py:29-36 via monkey-patched randn_like
+    fs = ForwardSampler(timesteps=1000, scale=0.5)
+    x0 = torch.from_numpy(prng.normal(SEED_X, "qs/x0", 4 * 3 * 4 * 8 * 3).reshape(4, 3, 4, 8, 3))
+    eps = torch.from_numpy(prng.normal(SEED_X, "qs/eps", 4 * 3 * 4 * 8 * 3).reshape(4, 3, 4, 8, 3))
+    t = torch.tensor([0, 17, 500, 999])
+    orig = torch.randn_like
+    torch.randn_like = lambda x, **kw: eps.clone()
+    try:
+        xt, e = fs(x0, t)
+    finally:
+        torch.randn_like = orig
+    assert torch.equal(e, eps)
+    d["qsample/t"] = t.numpy()
+    d["qsample/xt"] = xt.numpy()
+    np.savez_compressed(os.path.join(out, "schedule.npz"), **d)
+    print("schedule.npz", len(d))
+
+
+NARROW = dict(H=4, W=8, P=5, F=3, B=2)
+
+
+def narrow_cfg(C):
+    return spec.UNetConfig(C, C, 1, 8, (1, 2, 4), (False, False, True, False), 0.1, 4, "Past")
+
+
+def gen_ops(out):
+    from models.backbones import layers as RL
+    import torch.nn as nn
+    for C in (3, 4):
+        cfg = narrow_cfg(C)
+        params = spec.init_params(cfg, SEED_W)
+        net = ref_unet(cfg, params)
+        g = NARROW
+        past, fut = synth_inputs(g["B"], C, g["H"], g["W"], g["P"], g["F"], f"narrow{C}")
+        t = np.array([999, 3], dtype=np.int64)
+        cap = {}
+        with_inputs = {"encoder_blocks.0.conv_1", "encoder_blocks.1.downsample", "encoder_blocks.2.match_input",
+                       "encoder_blocks.0.normalize_1", "decoder_blocks.2", "encoder_blocks.4.attention.mhsa",
+                       "encoder_blocks.4.attention", "encoder_blocks.0", "encoder_blocks.4", "decoder_blocks.0",
+                       "decoder_blocks.3", "final"}
+        kinds = (nn.Conv3d, nn.GroupNorm, nn.MultiheadAttention, RL.ResnetBlock, RL.AttentionBlock,
+                 RL.DownSample, RL.UpSample, nn.Sequential, nn.Linear)
+
+        def hook(name):
+            def fn(mod, inp, outp):
+                o = outp[0] if isinstance(outp, tuple) else outp
+                cap[f"{name}/out"] = o.detach().numpy().copy()
+                if name in with_inputs:
+                    cap[f"{name}/in"] = inp[0].detach().numpy().copy()
+                    if isinstance(mod, RL.ResnetBlock):
+                        cap[f"{name}/temb"] = inp[1].detach().numpy().copy()
+            return fn
+
+        for name, mod in net.named_modules():
+            if name and isinstance(mod, kinds):
+                mod.register_forward_hook(hook(name))
+        with torch.inference_mode():
+            y = net(torch.from_numpy(fut), torch.from_numpy(t), torch.from_numpy(past))
+        cap["t"] = t
+        cap["out"] = y.numpy()
+        np.savez_compressed(os.path.join(out, f"ops_c{C}.npz"), **cap)
+        print(f"ops_c{C}.npz", len(cap), sum(v.nbytes for v in cap.values()) // 1024, "KiB")
+
+
+FULL_GRIDS = {"atc": (12, 36), "cr120": (28, 24), "atc2x": (24, 72)}
+
+
+def full_cfg(C):
+    return spec.UNetConfig(C, C, 1, 32, (1, 2, 4), (False, False, True, False), 0.1, 4, "Past")
+
+
+def gen_fwd(out):
+    d = {}
+    for C in (3, 4):
+        cfg = full_cfg(C)
+        net = ref_unet(cfg, spec.init_params(cfg, SEED_W))
+        for gname, (H, W) in FULL_GRIDS.items():
+            if C == 4 and gname != "atc":
+                continue
+            past, fut = synth_inputs(2, C, H, W, 5, 3, f"full/{gname}/c{C}")
+            t = np.array([999, 17], dtype=np.int64)
+            with torch.inference_mode():
+                y = net(torch.from_numpy(fut), torch.from_numpy(t), torch.from_numpy(past))
+            d[f"{gname}_c{C}/t"] = t
+            d[f"{gname}_c{C}/out"] = y.numpy()
+            print("fwd", gname, C, float(y.abs().max()))
+    np.savez_compressed(os.path.join(out, "fwd.npz"), **d)
+
+
+def loop_noise(tag, B, per, t):
+    return prng.normal_per_sample(SEED_X, f"z/{tag}", np.arange(B), per, step=t)
+
+
+def gen_loop(out):
+    AttrDict = _placeholders()
+    import yaml
+    from models.diffusion import ddpm as RD
+    cfg_yaml = AttrDict(yaml.safe_load(open(os.path.join(REF, "config", "ATC.yml"))))
+    C, H, W, P, F, B = 3, 12, 36, 5, 3, 2
+    ucfg = full_cfg(C)
+    params = spec.init_params(ucfg, SEED_W)
+    d = {}
+
+    def run(tag, T, sampler, guidance="None", lam=0.0, divider=None, sigma=None, keep=()):
+        cfg = AttrDict(yaml.safe_load(open(os.path.join(REF, "config", "ATC.yml"))))
+        cfg.MODEL.DDPM.TIMESTEPS = T
+        cfg.MODEL.DDPM.GUIDANCE = guidance
+        cfg.MODEL.DDPM.LAMBDA_GUIDANCE = lam
+        if sigma is not None:
+            cfg.MODEL.DDPM.SIGMA = sigma
+        model = RD.DDPM_model(cfg, "DDPM-UNet", C)
+        model.denoiser.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        sampler_obj = RD.DDPM(timesteps=T, scale=cfg.MODEL.DDPM.SCALE)
+        per = C * H * W * F
+        past = torch.from_numpy(prng.normal(SEED_X, f"past/loop/{tag}", B * C * H * W * P).reshape(B, C, H, W, P))
+        x_T = prng.normal_per_sample(SEED_X, f"xT/{tag}", np.arange(B), per).reshape(B, C, H, W, F)
+        # The reference draws x_T with torch.randn and z_t with torch.randn_like
+        # (ddpm.py:27,211,264).  Inject ours by patching those two entry points
+        # while the reference's own loop runs; the visited t is recovered from
+        # the call order.
+        if sampler == "DDPM":
+            order = [t for t in reversed(range(T)) if t > 0]
+        else:
+            taus = np.arange(0, T - 1, divider)
+            order = list(reversed(list(taus)))
+        calls = {"n": 0}
+        hist = {}
+
+        def fake_randn(*a, **kw):
+            return torch.from_numpy(x_T.copy())
+
+        def fake_randn_like(x, **kw):
+            t = int(order[calls["n"]])
+            calls["n"] += 1
+            return torch.from_numpy(loop_noise(tag, B, per, t).reshape(x.shape))
+
+        o1, o2 = torch.randn, torch.randn_like
+        torch.randn, torch.randn_like = fake_randn, fake_randn_like
+        try:
+            if sampler == "DDPM":
+                x, h = model._generate_ddpm(past, sampler_obj, B, history=bool(keep))
+                if keep:   # history = [x_T, x after t=T-1, ..., x after t=0]
+                    for t in keep:
+                        hist[t] = h[1 + (T - 1 - t)].numpy().copy()
+            else:
+                x, _ = model._generate_ddim(past, taus, sampler_obj, B)
+        finally:
+            torch.randn, torch.randn_like = o1, o2
+        assert calls["n"] == len(order), (calls, len(order))
+        d[f"{tag}/x0"] = x.numpy()
+        for t, v in hist.items():
+            d[f"{tag}/x_after_t{t}"] = v
+        print("loop", tag, float(x.abs().max()))
+
+    run("ddpm50", 50, "DDPM")
+    run("ddpm20_sparsity", 20, "DDPM", guidance="Sparsity", lam=0.004)
+    run("ddim1000_div100", 1000, "DDIM", divider=100, sigma=0.001)
+    run("ddim1000_div100_sparsity", 1000, "DDIM", divider=100, sigma=0.001, guidance="Sparsity", lam=0.004)
+    run("ddpm1000", 1000, "DDPM", keep=(999, 900, 500, 0))
+    np.savez_compressed(os.path.join(out, "loop.npz"), **d)
+
+
+def gen_train(out):
+    """One fp32 training step of the narrow model: ddpm.py:111-121 with t, eps and
+    the Dropout3d masks injected (autocast is a no-op on CPU)."""
+    import torch.nn as nn
+    from models.backbones import layers as RL
+    from models.diffusion.forward import ForwardSampler
+    C = 3
+    cfg = narrow_cfg(C)
+    params = spec.init_params(cfg, SEED_W)
+    net = ref_unet(cfg, params).train()
+    g = NARROW
+    B = 4
+    past, fut = synth_inputs(B, C, g["H"], g["W"], g["P"], g["F"], "train")
+    eps = prng.normal(SEED_X, "train/eps", fut.size).reshape(fut.shape)
+    t = np.array([0, 250, 731, 999], dtype=np.int64)
+    p = cfg.dropout_rate
+
+    class FixedDrop(nn.Module):
+        def __init__(self, mask):
+            super().__init__()
+            self.mask = mask
+
+        def forward(self, x):
+            return x * self.mask[:, :, None, None, None]
+
+    masks = {}
+    for name, mod in net.named_modules():
+        if isinstance(mod, RL.ResnetBlock):
+            u = prng.uniform_pm1(SEED_X, f"drop/{name}", B * mod.out_channels).reshape(B, mod.out_channels)
+            keep = ((u * 0.5 + 0.5) >= p).astype(np.float32) / np.float32(1.0 - p)
+            masks[name] = keep
+            mod.dropout = FixedDrop(torch.from_numpy(keep))
+    fs = ForwardSampler(timesteps=1000, scale=0.5)
+    o = torch.randn_like
+    torch.randn_like = lambda x, **kw: torch.from_numpy(eps.copy())
+    try:
+        xt, e = fs(torch.from_numpy(fut), torch.from_numpy(t))
+    finally:
+        torch.randn_like = o
+    pred = net(xt, torch.from_numpy(t), torch.from_numpy(past))
+    loss = torch.nn.functional.mse_loss(pred, e)
+    loss.backward()
+    d = {"t": t, "loss": np.float32(loss.item()), "pred": pred.detach().numpy()}
+    for name, prm in net.named_parameters():
+        if prm.grad is not None:
+            d[f"gnorm/{name}"] = np.float32(prm.grad.norm().item())
+    for k in ("first.weight", "final.2.weight", "encoder_blocks.4.attention.mhsa.in_proj_weight",
+              "encoder_blocks.0.conv_1.weight", "decoder_blocks.7.normalize_1.weight",
+              "time_embeddings.time_blocks.1.weight"):
+        d[f"grad/{k}"] = dict(net.named_parameters())[k].grad.numpy()
+    np.savez_compressed(os.path.join(out, "train.npz"), **d)
+    print("train loss", float(loss))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="schedule,ops,fwd,loop,train")
+    ap.add_argument("--out", default=HERE)
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    todo = set(a.only.split(","))
+    if "schedule" in todo:
+        gen_schedule(a.out)
+    if "ops" in todo:
+        gen_ops(a.out)
+    if "fwd" in todo:
+        gen_fwd(a.out)
+    if "train" in todo:
+        gen_train(a.out)
+    if "loop" in todo:
+        gen_loop(a.out)
+
+
+if __name__ == "__main__":
+    main()
