@@ -10,3 +10,22 @@ is imported through the root-level shim module `crowdmod_ddpm_4d_amd`.
 from . import prng, spec  # noqa: F401
 
 __all__ = ["prng", "spec"]
+from . import config  # noqa: F401,E402
+
+
+def __getattr__(name):
+    # native-backed modules are imported lazily so that `import crowdmod_ddpm_4d_amd`
+    # works on a box without the built library (e.g. for prng / spec / config only)
+    if name in ("native", "unet", "diffusion", "ddpm_model"):
+        import importlib
+        return importlib.import_module(f"{__name__}.{name}")
+    if name in ("UNet",):
+        from .unet import UNet
+        return UNet
+    if name in ("DDPM", "ForwardSampler"):
+        from . import diffusion
+        return getattr(diffusion, name)
+    if name == "DDPM_model":
+        from .ddpm_model import DDPM_model
+        return DDPM_model
+    raise AttributeError(name)

@@ -1,0 +1,98 @@
+// Internal launch interface between the host orchestration (cm_model.cpp) and
+// the gfx950 kernels (cm_conv.hip, cm_misc.hip).  Not part of the public ABI.
+//
+// Internal activation layout: channels-last  [B][Z][Y][X][C]  fp32 with
+//   Z = frames (reference L), Y = rows (reference H), X = cols (reference W)
+// and C a multiple of 8.  A 3-D convolution is invariant under a consistent
+// permutation of the spatial axes of input and kernel, so tap (dz,dy,dx) of the
+// internal kernel is element [kH=dy][kW=dx][kL=dz] of the reference weight.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cm {
+
+// One implicit-GEMM convolution launch:  out[m][n] = sum_k A[m][k] * W[k][n]
+//   m = output voxel (b,z,y,x), n = output channel, k = (tap, input channel).
+struct ConvArgs {
+  const float *src0;   // [B][Zs][Ys][Xs][C0]
+  const float *src1;   // second source of a channel concat (torch.cat dim=1), or null
+  int C0, C1;          // multiples of CK
+  const float *gn;     // [B][2][C0+C1] per-(sample,channel) scale row, shift row; or null
+  int silu;            // apply SiLU after the affine (GroupNorm->SiLU fused on load)
+  const float *wfrag;  // weights in MFMA fragment order (see pack_conv_weights)
+  const float *bias;   // [Co padded to TN]
+  const float *temb;   // [rows][temb_stride] time-embedding projection table, or null
+  int temb_stride;
+  const long long *tidx;  // [B] timestep per sample (row of temb)
+  const float *resid;  // residual, channels-last with channel stride res_cs, or null
+  int res_cs;
+  float *out;          // [B][Zo][Yo][Xo][out_cs]
+  int out_cs;
+  int Co;              // valid output channels
+  int B;
+  int Zs, Ys, Xs;      // source dims (before nearest-upsample)
+  int Zo, Yo, Xo;      // output dims
+  int ntaps;           // 27 (3x3x3, zero pad 1) or 1 (1x1x1)
+  int stride;          // 1 or 2
+  int ups;             // 1: source is nearest-upsampled x2 on the fly
+  int bs, bz, by, bx;  // output box of one workgroup: samples x z x y x x
+  int nts, ntz, nty, ntx;  // number of boxes along each of those
+  int CK;              // channel chunk staged per pass: 8, 16 or 32
+  int nch0, nch1;      // chunks in src0 / src1
+  float *stat_part;    // optional fused per-channel statistics partials (unused in v1)
+};
+
+size_t conv_lds_bytes(const ConvArgs &a, int MB, int NB);
+// MB x NB = number of 32x32 accumulator blocks per wave (workgroup tile 32MB x 32NB).
+hipError_t launch_conv(const ConvArgs &a, int MB, int NB, hipStream_t st);
+bool conv_variant_exists(int MB, int NB);
+
+// ---- small kernels --------------------------------------------------------
+// Per-(sample, slice, channel) mean and M2 of a channels-last tensor.
+//   part [B][nslice][C][2]
+hipError_t launch_chan_stats(const float *x, int B, int V, int C, int nslice, float *part, hipStream_t st);
+// Combine partial statistics of (up to) two concatenated tensors into GroupNorm
+// scale/shift rows:  gn[b][0][c] = rstd_g*gamma_c ; gn[b][1][c] = beta_c - mean_g*rstd_g*gamma_c
+hipError_t launch_gn_finalize(const float *part0, int C0, const float *part1, int C1, int nslice, int V,
+                              const float *gamma, const float *beta, int groups, float eps, float *gn, int B,
+                              hipStream_t st);
+// reference layout [B,C,H,W,P] + [B,C,H,W,F]  ->  channels-last [B][P+F][H][W][8]
+hipError_t launch_assemble_input(const float *past, const float *future, float *x8, int B, int C, int H, int W,
+                                 int P, int F, int which /*1 past,2 future,3 both*/, hipStream_t st);
+// channels-last eps [B][L][H][W][cs] frames >= P  ->  reference layout [B,C,H,W,F]
+hipError_t launch_extract_output(const float *eps_cl, int cs, float *out, int B, int C, int H, int W, int P, int F,
+                                 hipStream_t st);
+// Time-embedding MLP + all per-block dense_1 projections, one row per t value:
+//   out[row][0..nproj) = Wd @ silu(W2 @ silu(W1 @ table[t_row] + b1) + b2) + bd
+hipError_t launch_time_mlp(const float *table, const float *W1, const float *b1, const float *W2, const float *b2,
+                           const float *Wd, const float *bd, int te, int tx, int nproj, int nrows, float *temb_raw,
+                           float *out, hipStream_t st);
+// softmax(q k^T / sqrt(d)) v per (sample, head); qkv channels-last [B][S][3E]
+hipError_t launch_attn_core(const float *qkv, float *out, int B, int S, int E, int heads, hipStream_t st);
+
+struct StepArgs {
+  float *x;             // [B,C,H,W,F] reference layout, updated in place
+  const float *eps_cl;  // channels-last UNet output [B][L][H][W][cs]
+  int cs;
+  float *x8;            // UNet input tensor [B][L][H][W][8]: future frames rewritten with the new x
+  const float *noise;   // [B,C,H,W,F] or null -> Philox
+  float *hist;          // optional copy of the new x
+  int B, C, H, W, P, F;
+  float c_x, c_eps, c_noise;  // x' = c_x * x + c_eps * eps + c_noise * z
+  float guid;                 // sparsity guidance: x'[:,0] -= guid * sign(x'[:,0])
+  unsigned long long seed;
+  long long sample_id_base;
+  int step;             // Philox stream index of this step
+  int draw;             // 0: z = 0
+};
+hipError_t launch_sampler_step(const StepArgs &a, hipStream_t st);
+hipError_t launch_q_sample(const float *x0, const long long *t, const float *eps, const float *sab, const float *s1m,
+                           float *xt, int B, long long per, hipStream_t st);
+hipError_t launch_fill_t(long long *t, int B, long long value, hipStream_t st);
+hipError_t launch_randn(float *x, int B, long long per, unsigned long long seed, long long sample_id_base, int step,
+                        hipStream_t st);
+// generic strided copy channels-last -> reference layout (debug hook)
+hipError_t launch_cl_to_ref(const float *x_cl, int cs, float *out, int B, int C, int Z, int Y, int X, hipStream_t st);
+
+}  // namespace cm

@@ -1,0 +1,472 @@
+// Small HBM-/latency-bound kernels around the convolutions: GroupNorm statistics,
+// layout changes at the ABI edge, the time-embedding MLP, the attention core and
+// the sampler updates.  gfx950 only (64-wide wavefronts).
+#include "cm_kernels.h"
+
+namespace cm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+
+// Chan et al. pairwise combination of (n, mean, M2) triples.
+__device__ __forceinline__ void chan_combine(float &n, float &mean, float &m2, float nb, float meanb, float m2b) {
+  if (nb == 0.f) return;
+  const float nt = n + nb;
+  const float d = meanb - mean;
+  const float f = nb / nt;
+  mean += d * f;
+  m2 += m2b + d * d * n * f;
+  n = nt;
+}
+
+// --------------------------------------------------------------------------------
+// Per-channel statistics of a channels-last tensor x[B][V][C] (GroupNorm stats are
+// assembled from them in gn_finalize so that any channel grouping -- including
+// groups that straddle a torch.cat boundary, unet.py:160 + layers.py:30 -- works).
+// grid (nslice, B), 256 threads; thread = (channel quad, voxel lane).
+// Each thread runs a shifted two-moment accumulation (pivot = its first value),
+// threads are merged with Chan's formula through LDS in a fixed order.
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chan_stats_kernel(const float *__restrict__ x, int V, int C, int nslice,
+                                                         float *__restrict__ part) {
+  __shared__ float sh[256 * 4 * 3];
+  const int b = blockIdx.y, sl = blockIdx.x;
+  const int Q = C >> 2;                 // channel quads
+  const int tid = threadIdx.x;
+  const int vs = (V + nslice - 1) / nslice;
+  const int vbeg = sl * vs, vend = min(V, vbeg + vs);
+  const int nvl = 256 / Q > 0 ? 256 / Q : 1;  // voxel lanes per quad
+  const int q = tid % Q, vl = tid / Q;
+  float n = 0.f;
+  f32x4 piv = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  if (vl < nvl && Q <= 256) {
+    const float *xb = x + ((size_t)b * V) * C + 4 * q;
+    bool first = true;
+    for (int v = vbeg + vl; v < vend; v += nvl) {
+      const f32x4 val = *reinterpret_cast<const f32x4 *>(xb + (size_t)v * C);
+      if (first) { piv = val; first = false; }
+      const f32x4 d = val - piv;
+      s1 += d;
+      s2 += d * d;
+      n += 1.f;
+    }
+  }
+  // to (n, mean, M2) per component
+  float mean[4], m2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (n > 0.f) {
+      const float md = s1[i] / n;
+      mean[i] = piv[i] + md;
+      m2[i] = s2[i] - s1[i] * md;
+      if (m2[i] < 0.f) m2[i] = 0.f;
+    } else { mean[i] = 0.f; m2[i] = 0.f; }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sh[(tid * 4 + i) * 3 + 0] = n;
+    sh[(tid * 4 + i) * 3 + 1] = mean[i];
+    sh[(tid * 4 + i) * 3 + 2] = m2[i];
+  }
+  __syncthreads();
+  // one thread per channel merges the voxel lanes in order
+  for (int c = tid; c < C; c += 256) {
+    const int qq = c >> 2, i = c & 3;
+    float N = 0.f, M = 0.f, S2 = 0.f;
+    for (int l = 0; l < nvl; ++l) {
+      const int t = l * Q + qq;
+      if (t < 256) chan_combine(N, M, S2, sh[(t * 4 + i) * 3 + 0], sh[(t * 4 + i) * 3 + 1], sh[(t * 4 + i) * 3 + 2]);
+    }
+    float *p = part + (((size_t)b * nslice + sl) * C + c) * 2;
+    p[0] = M;
+    p[1] = S2;
+  }
+}
+
+hipError_t launch_chan_stats(const float *x, int B, int V, int C, int nslice, float *part, hipStream_t st) {
+  if (C % 4 != 0 || C / 4 > 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(chan_stats_kernel, dim3(nslice, B), dim3(256), 0, st, x, V, C, nslice, part);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
+// GroupNorm finalisation: nn.GroupNorm(8, C) statistics (biased variance, eps)
+// over the channel-concatenation of up to two tensors (layers.py:30,41,9; unet.py:119)
+// folded with the affine into one scale/shift pair per (sample, channel).
+// grid B, 256 threads.
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ p0, int C0,
+                                                          const float *__restrict__ p1, int C1, int nslice, int V,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, int groups, float eps,
+                                                          float *__restrict__ gn) {
+  extern __shared__ float sm[];  // [Ctot] mean, [Ctot] m2, [groups] gmean, [groups] grstd
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Ct = C0 + C1;
+  float *cmean = sm, *cm2 = sm + Ct, *gmean = sm + 2 * Ct, *grstd = gmean + groups;
+  const int vs = (V + nslice - 1) / nslice;
+  for (int c = tid; c < Ct; c += 256) {
+    const float *p;
+    int Cx, cc;
+    if (c < C0) { p = p0; Cx = C0; cc = c; } else { p = p1; Cx = C1; cc = c - C0; }
+    float N = 0.f, M = 0.f, S2 = 0.f;
+    for (int s = 0; s < nslice; ++s) {
+      const int cnt = min(V, (s + 1) * vs) - s * vs;
+      if (cnt <= 0) break;
+      const float *q = p + (((size_t)b * nslice + s) * Cx + cc) * 2;
+      chan_combine(N, M, S2, (float)cnt, q[0], q[1]);
+    }
+    cmean[c] = M;
+    cm2[c] = S2;
+  }
+  __syncthreads();
+  const int cg = Ct / groups;
+  if (tid < groups) {
+    float N = 0.f, M = 0.f, S2 = 0.f;
+    for (int i = 0; i < cg; ++i) chan_combine(N, M, S2, (float)V, cmean[tid * cg + i], cm2[tid * cg + i]);
+    gmean[tid] = M;
+    grstd[tid] = rsqrtf(S2 / N + eps);
+  }
+  __syncthreads();
+  for (int c = tid; c < Ct; c += 256) {
+    const int g = c / cg;
+    const float sc = grstd[g] * gamma[c];
+    gn[((size_t)b * 2 + 0) * Ct + c] = sc;
+    gn[((size_t)b * 2 + 1) * Ct + c] = beta[c] - gmean[g] * sc;
+  }
+}
+
+hipError_t launch_gn_finalize(const float *part0, int C0, const float *part1, int C1, int nslice, int V,
+                              const float *gamma, const float *beta, int groups, float eps, float *gn, int B,
+                              hipStream_t st) {
+  const int Ct = C0 + C1;
+  if (Ct % groups != 0) return hipErrorInvalidValue;
+  const size_t smem = (size_t)(2 * Ct + 2 * groups) * sizeof(float);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), smem, st, part0, C0, part1, C1, nslice, V, gamma, beta,
+                     groups, eps, gn);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
+// ABI edge: reference layout [B,C,H,W,L] <-> channels-last [B][L][H][W][8].
+// unet.py:138 (cat past||future on L) and unet.py:166 (keep frames >= P) are folded in.
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_input_kernel(const float *__restrict__ past,
+                                                             const float *__restrict__ fut, float *__restrict__ x8,
+                                                             int B, int C, int H, int W, int P, int F, int which) {
+  const int L = P + F;
+  const long long total = (long long)B * L * H * W;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int w = (int)(i % W);
+  long long q = i / W;
+  const int hh = (int)(q % H); q /= H;
+  const int l = (int)(q % L);
+  const int b = (int)(q / L);
+  const bool is_past = l < P;
+  if (is_past && !(which & 1)) return;
+  if (!is_past && !(which & 2)) return;
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float val = 0.f;
+    if (c < C) {
+      const size_t base = (((size_t)b * C + c) * H + hh) * W + w;
+      val = is_past ? past[base * P + l] : fut[base * F + (l - P)];
+    }
+    v[c] = val;
+  }
+  f32x4 *dst = reinterpret_cast<f32x4 *>(x8 + (size_t)i * 8);
+  dst[0] = f32x4{v[0], v[1], v[2], v[3]};
+  dst[1] = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+hipError_t launch_assemble_input(const float *past, const float *future, float *x8, int B, int C, int H, int W, int P,
+                                 int F, int which, hipStream_t st) {
+  const long long total = (long long)B * (P + F) * H * W;
+  hipLaunchKernelGGL(assemble_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, past, future, x8,
+                     B, C, H, W, P, F, which);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void extract_output_kernel(const float *__restrict__ eps_cl, int cs,
+                                                             float *__restrict__ out, int B, int C, int H, int W,
+                                                             int P, int F) {
+  const long long total = (long long)B * C * H * W * F;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int f = (int)(i % F);
+  long long q = i / F;
+  const int w = (int)(q % W); q /= W;
+  const int hh = (int)(q % H); q /= H;
+  const int c = (int)(q % C);
+  const int b = (int)(q / C);
+  const int L = P + F;
+  out[i] = eps_cl[((((size_t)b * L + (P + f)) * H + hh) * W + w) * cs + c];
+}
+
+hipError_t launch_extract_output(const float *eps_cl, int cs, float *out, int B, int C, int H, int W, int P, int F,
+                                 hipStream_t st) {
+  const long long total = (long long)B * C * H * W * F;
+  hipLaunchKernelGGL(extract_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, eps_cl, cs, out,
+                     B, C, H, W, P, F);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void cl_to_ref_kernel(const float *__restrict__ x, int cs, float *__restrict__ out,
+                                                        int B, int C, int Z, int Y, int X) {
+  const long long total = (long long)B * C * Y * X * Z;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int z = (int)(i % Z);
+  long long q = i / Z;
+  const int xx = (int)(q % X); q /= X;
+  const int y = (int)(q % Y); q /= Y;
+  const int c = (int)(q % C);
+  const int b = (int)(q / C);
+  out[i] = x[((((size_t)b * Z + z) * Y + y) * X + xx) * cs + c];
+}
+
+hipError_t launch_cl_to_ref(const float *x_cl, int cs, float *out, int B, int C, int Z, int Y, int X, hipStream_t st) {
+  const long long total = (long long)B * C * Y * X * Z;
+  hipLaunchKernelGGL(cl_to_ref_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x_cl, cs, out, B, C,
+                     Z, Y, X);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
+// Time embedding (embeddings.py:24-30) followed by every ResnetBlock's
+// dense_1(SiLU(temb)) (layers.py:35,62), one workgroup per table row.  It depends
+// only on t and the weights, so the host evaluates it once for all 1000 rows at
+// load time and the conv epilogues index the result by t[b].
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_mlp_kernel(const float *__restrict__ table, const float *__restrict__ W1,
+                                                       const float *__restrict__ b1, const float *__restrict__ W2,
+                                                       const float *__restrict__ b2, const float *__restrict__ Wd,
+                                                       const float *__restrict__ bd, int te, int tx, int nproj,
+                                                       float *__restrict__ temb_raw, float *__restrict__ out) {
+  extern __shared__ float sm[];  // e[te], h1[tx], h2[tx]
+  float *e = sm, *h1 = sm + te, *h2 = h1 + tx;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < te; i += 256) e[i] = table[(size_t)row * te + i];
+  __syncthreads();
+  for (int o = tid; o < tx; o += 256) {
+    float acc = b1[o];
+    for (int i = 0; i < te; ++i) acc = fmaf(W1[(size_t)o * te + i], e[i], acc);
+    h1[o] = silu_f(acc);
+  }
+  __syncthreads();
+  for (int o = tid; o < tx; o += 256) {
+    float acc = b2[o];
+    for (int i = 0; i < tx; ++i) acc = fmaf(W2[(size_t)o * tx + i], h1[i], acc);
+    if (temb_raw) temb_raw[(size_t)row * tx + o] = acc;
+    h2[o] = silu_f(acc);
+  }
+  __syncthreads();
+  for (int o = tid; o < nproj; o += 256) {
+    float acc = bd[o];
+    for (int i = 0; i < tx; ++i) acc = fmaf(Wd[(size_t)o * tx + i], h2[i], acc);
+    out[(size_t)row * nproj + o] = acc;
+  }
+}
+
+hipError_t launch_time_mlp(const float *table, const float *W1, const float *b1, const float *W2, const float *b2,
+                           const float *Wd, const float *bd, int te, int tx, int nproj, int nrows, float *temb_raw,
+                           float *out, hipStream_t st) {
+  const size_t smem = (size_t)(te + 2 * tx) * sizeof(float);
+  hipLaunchKernelGGL(time_mlp_kernel, dim3(nrows), dim3(256), smem, st, table, W1, b1, W2, b2, Wd, bd, te, tx, nproj,
+                     temb_raw, out);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
+// Attention core of nn.MultiheadAttention (layers.py:16): per (sample, head)
+// softmax(q k^T / sqrt(d)) v with d = 32, S = H*W*L tokens at quarter resolution
+// (54 / 84 / 216).  One workgroup per (head, sample): K and V live in LDS, each
+// thread owns one query row (online softmax).  The in/out projections run on the
+// MFMA 1x1x1 conv path.
+// --------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_core_kernel(const float *__restrict__ qkv, float *__restrict__ out, int S,
+                                                        int E) {
+  extern __shared__ float sm[];  // K[S][D], V[S][D]
+  float *Ks = sm, *Vs = sm + (size_t)S * D;
+  const int hd = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float *base = qkv + (size_t)b * S * 3 * E;
+  for (int i = tid; i < S * (D / 4); i += 256) {
+    const int s = i / (D / 4), d4 = i % (D / 4);
+    const f32x4 k = *reinterpret_cast<const f32x4 *>(base + (size_t)s * 3 * E + E + hd * D + 4 * d4);
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (size_t)s * 3 * E + 2 * E + hd * D + 4 * d4);
+    *reinterpret_cast<f32x4 *>(Ks + s * D + 4 * d4) = k;
+    *reinterpret_cast<f32x4 *>(Vs + s * D + 4 * d4) = v;
+  }
+  __syncthreads();
+  const float scale = rsqrtf((float)D);
+  for (int row = tid; row < S; row += 256) {
+    float q[D], o[D];
+    const float *qp = base + (size_t)row * 3 * E + hd * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { q[d] = qp[d] * scale; o[d] = 0.f; }
+    float mx = -3.0e38f, l = 0.f;
+    for (int j = 0; j < S; ++j) {
+      float sc = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) sc = fmaf(q[d], Ks[j * D + d], sc);
+      if (sc > mx) {
+        const float corr = __expf(mx - sc);
+        l *= corr;
+#pragma unroll
+        for (int d = 0; d < D; ++d) o[d] *= corr;
+        mx = sc;
+      }
+      const float p = __expf(sc - mx);
+      l += p;
+#pragma unroll
+      for (int d = 0; d < D; ++d) o[d] = fmaf(p, Vs[j * D + d], o[d]);
+    }
+    const float inv = 1.0f / l;
+    float *op = out + ((size_t)b * S + row) * E + hd * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) op[d] = o[d] * inv;
+  }
+}
+
+hipError_t launch_attn_core(const float *qkv, float *out, int B, int S, int E, int heads, hipStream_t st) {
+  const int D = E / heads;
+  const size_t smem = (size_t)2 * S * D * sizeof(float);
+  if (smem > 160 * 1024) return hipErrorInvalidValue;
+#define CM_ATTN(DD)                                                                                         \
+  if (D == DD) {                                                                                            \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_core_kernel<DD>),                \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);             \
+    if (e != hipSuccess) return e;                                                                          \
+    hipLaunchKernelGGL((attn_core_kernel<DD>), dim3(heads, B), dim3(256), smem, st, qkv, out, S, E);          \
+    return hipGetLastError();                                                                               \
+  }
+  CM_ATTN(8) CM_ATTN(16) CM_ATTN(32) CM_ATTN(64)
+#undef CM_ATTN
+  return hipErrorInvalidValue;
+}
+
+// --------------------------------------------------------------------------------
+// Device RNG: Philox4x32-10 keyed by the seed, counter = (element quad, global
+// sample id, step, stream).  Independent of batch sharding: sample i of the job
+// draws the same numbers on 1 GPU and on 8.
+// --------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned out[4]) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned long long p0 = 0xD2511F53ull * c0;
+    const unsigned long long p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    const unsigned n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    const unsigned n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float philox_normal(unsigned long long seed, long long sample, int step, long long elem) {
+  unsigned r[4];
+  philox4x32_10((unsigned)(elem >> 1), (unsigned)sample, (unsigned)step, (unsigned)((sample >> 32) ^ 0x5eed),
+                (unsigned)seed, (unsigned)(seed >> 32), r);
+  // Box-Muller on one pair; element parity picks cos / sin branch
+  const float u1 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float rad = sqrtf(-2.0f * __logf(u1));
+  const float ang = 6.283185307179586f * u2;
+  return (elem & 1) ? rad * __sinf(ang) : rad * __cosf(ang);
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float *__restrict__ x, long long per, long long total,
+                                                    unsigned long long seed, long long sample_id_base, int step) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long b = i / per, e = i - b * per;
+  x[i] = philox_normal(seed, sample_id_base + b, step, e);
+}
+
+hipError_t launch_randn(float *x, int B, long long per, unsigned long long seed, long long sample_id_base, int step,
+                        hipStream_t st) {
+  const long long total = (long long)B * per;
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, per, total, seed,
+                     sample_id_base, step);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
+// One reverse-process update for both samplers, written as
+//     x' = c_x * x + c_eps * eps_hat + c_noise * z          (+ sparsity guidance)
+// DDPM.step (ddpm.py:31-37):  c_x = 1/sqrt(alpha_t), c_eps = -c_x*beta_t/sqrt(1-abar_t),
+//                             c_noise = sqrt(beta_t)
+// DDIM Eq.12 (ddpm.py:262-265): c_x = sab_prev/sab_t, c_eps = sqrt(1-sab_prev^2-sigma^2)
+//                             - c_x*s1m_t, c_noise = sigma
+// guidance (ddpm.py:223-226, guidance.py:4-8): x'[:,0] -= guid * sign(x'[:,0]).
+// Besides x (reference layout) it rewrites the future frames of the channels-last
+// UNet input so the next step needs no re-assembly.
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs a) {
+  const long long per = (long long)a.C * a.H * a.W * a.F;
+  const long long total = per * a.B;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long b = i / per, e = i - b * per;
+  const int f = (int)(e % a.F);
+  long long q = e / a.F;
+  const int w = (int)(q % a.W); q /= a.W;
+  const int hh = (int)(q % a.H);
+  const int c = (int)(q / a.H);
+  const int L = a.P + a.F;
+  const size_t cl = ((((size_t)b * L + (a.P + f)) * a.H + hh) * a.W + w);
+  const float eps = a.eps_cl[cl * a.cs + c];
+  float z = 0.f;
+  if (a.draw) z = a.noise ? a.noise[i] : philox_normal(a.seed, a.sample_id_base + b, a.step, e);
+  // evaluation order mirrors the reference expression tree where it matters for rounding
+  float xn = a.c_x * a.x[i] + a.c_eps * eps + a.c_noise * z;
+  if (a.guid != 0.f && c == 0) xn -= a.guid * (xn > 0.f ? 1.f : (xn < 0.f ? -1.f : 0.f));
+  a.x[i] = xn;
+  if (a.x8) a.x8[cl * 8 + c] = xn;
+  if (a.hist) a.hist[i] = xn;
+}
+
+hipError_t launch_sampler_step(const StepArgs &a, hipStream_t st) {
+  const long long total = (long long)a.B * a.C * a.H * a.W * a.F;
+  hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void q_sample_kernel(const float *__restrict__ x0, const long long *__restrict__ t,
+                                                       const float *__restrict__ eps, const float *__restrict__ sab,
+                                                       const float *__restrict__ s1m, float *__restrict__ xt,
+                                                       long long per, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long b = i / per;
+  const long long tt = t[b];
+  xt[i] = sab[tt] * x0[i] + s1m[tt] * eps[i];
+}
+
+hipError_t launch_q_sample(const float *x0, const long long *t, const float *eps, const float *sab, const float *s1m,
+                           float *xt, int B, long long per, hipStream_t st) {
+  const long long total = (long long)B * per;
+  hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x0, t, eps, sab, s1m,
+                     xt, per, total);
+  return hipGetLastError();
+}
+
+__global__ void fill_t_kernel(long long *t, int B, long long v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < B) t[i] = v;
+}
+
+hipError_t launch_fill_t(long long *t, int B, long long value, hipStream_t st) {
+  hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, st, t, B, value);
+  return hipGetLastError();
+}
+
+}  // namespace cm

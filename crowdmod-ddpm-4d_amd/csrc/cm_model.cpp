@@ -1,0 +1,1129 @@
+// Host side of libcrowdmod_hip.so: model construction (mirrors the reference UNet
+// constructor, /root/reference/models/backbones/unet.py:11-122), weight packing
+// into MFMA fragment order, the launch sequence of one UNet forward
+// (unet.py:124-167, layers.py:55-78,12-18) and the on-device reverse loops
+// (models/diffusion/ddpm.py:206-282).  Everything here is plain C++ over the HIP
+// runtime; the public surface is the C ABI in include/crowdmod_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/crowdmod_hip.h"
+#include "cm_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+
+#define CM_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+constexpr int GN_GROUPS = 8;       // layers.py:9,30,41 ; unet.py:119
+constexpr float GN_EPS = 1e-5f;
+constexpr int ATTN_HEADS = 4;      // layers.py:10
+constexpr int TIME_ROWS = 1000;    // embeddings.py:7
+constexpr int MAX_SLICES = 16;
+
+enum KClass { K_CONV3 = 0, K_CONV1 = 1, K_NORM = 2, K_ATTN = 3, K_ELEM = 4, K_NCLASS = 8 };
+
+struct Param {
+  std::string name;
+  std::vector<int64_t> shape;
+  std::vector<float> host;
+  bool set = false;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+  }
+};
+
+// A channels-last activation [B][Z][Y][X][C] plus its per-channel statistics partials.
+struct Act {
+  std::string name;
+  float *d = nullptr;
+  int C = 0, Z = 0, Y = 0, X = 0;
+  float *part = nullptr;  // [B][nslice][C][2]
+  int nslice = 1;
+  int V() const { return Z * Y * X; }
+};
+
+struct BlockDesc {
+  int kind;  // 0 res, 1 down, 2 up
+  std::string prefix;
+  int cin, cout, attention, skip, level;
+};
+
+enum OpKind { OP_CONV, OP_STATS, OP_GNFIN, OP_ATTN };
+
+struct Op {
+  OpKind kind;
+  int cls;
+  // conv
+  cm::ConvArgs ca{};
+  int MB = 1, NB = 1;
+  int tuned_B = -1;
+  double flops_per_sample = 0;
+  // stats
+  const Act *act = nullptr;
+  // gn finalize
+  const Act *g0 = nullptr, *g1 = nullptr;
+  const float *gamma = nullptr, *beta = nullptr;
+  float *gn_out = nullptr;
+  // attention
+  const float *qkv = nullptr;
+  float *aout = nullptr;
+  int S = 0, E = 0;
+};
+
+}  // namespace
+
+struct cm_schedule {
+  int T = 0;
+  int device = 0;
+  std::vector<float> tab[6];
+  float *d_sab = nullptr, *d_s1m = nullptr;
+};
+
+struct cm_model {
+  cm_unet_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<Param> params;
+  std::map<std::string, int> pindex;
+  std::vector<BlockDesc> enc, bott, dec;
+  int final_ch = 0;
+  bool finalized = false;
+
+  std::vector<void *> allocs;
+  std::vector<std::unique_ptr<Act>> acts;
+  std::map<std::string, Act *> act_by_name;
+  std::vector<Op> ops;
+  std::map<std::string, float *> dparam;  // raw uploaded small tensors
+
+  // persistent device buffers
+  float *x8 = nullptr;          // UNet input [B][L][H][W][8]
+  Act *x8_act = nullptr;
+  float *eps_cl = nullptr;      // UNet output channels-last [B][L][H][W][8]
+  long long *tbuf = nullptr;    // [B] timestep per sample
+  float *temb_table = nullptr;  // [1000][nproj]
+  int nproj = 0;
+  float *xstate = nullptr;      // sampler state [B,C,H,W,F]
+  float *stage_past = nullptr, *stage_fut = nullptr, *stage_out = nullptr;  // host-variant staging
+  float *stage_noise = nullptr;
+  size_t stage_noise_cap = 0;
+  float *stage_hist = nullptr;
+  size_t stage_hist_cap = 0;
+
+  // profiling
+  bool profile = false;
+  float prof_ms[K_NCLASS] = {0};
+  int64_t prof_n[K_NCLASS] = {0};
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+
+  int L() const { return cfg.past_len + cfg.future_len; }
+  int64_t per_sample() const { return (int64_t)cfg.in_channels * cfg.rows * cfg.cols * cfg.future_len; }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------
+// construction
+// ------------------------------------------------------------------------------
+void add_param(cm_model *m, const std::string &name, std::vector<int64_t> shape) {
+  Param p;
+  p.name = name;
+  p.shape = std::move(shape);
+  p.host.assign((size_t)p.numel(), 0.f);
+  m->pindex[name] = (int)m->params.size();
+  m->params.push_back(std::move(p));
+}
+
+// Block wiring and state_dict names: same loop structure as unet.py:45-115.
+void build_plan(cm_model *m) {
+  const cm_unet_config &c = m->cfg;
+  const int base = c.base_channels, nres = c.n_levels;
+  const int64_t te = base, tx = (int64_t)base * c.time_multiple;
+  add_param(m, "time_embeddings.time_blocks.0.weight", {TIME_ROWS, te});
+  add_param(m, "time_embeddings.time_blocks.1.weight", {tx, te});
+  add_param(m, "time_embeddings.time_blocks.1.bias", {tx});
+  add_param(m, "time_embeddings.time_blocks.3.weight", {tx, tx});
+  add_param(m, "time_embeddings.time_blocks.3.bias", {tx});
+  add_param(m, "first.weight", {base, c.in_channels, 3, 3, 3});
+  add_param(m, "first.bias", {base});
+
+  std::vector<int> stack{base};
+  int cin = base, idx = 0;
+  for (int level = 0; level < nres; ++level) {
+    const int cout = base * c.channel_mult[level];
+    for (int r = 0; r < c.num_res_blocks; ++r) {
+      m->enc.push_back({0, "encoder_blocks." + std::to_string(idx++), cin, cout, c.apply_attention[level] != 0, 0, level});
+      cin = cout;
+      stack.push_back(cin);
+    }
+    if (level != nres - 1) {
+      m->enc.push_back({1, "encoder_blocks." + std::to_string(idx++), cin, cin, 0, 0, level});
+      stack.push_back(cin);
+    }
+  }
+  m->bott.push_back({0, "bottleneck_blocks.0", cin, cin, 1, 0, nres - 1});
+  m->bott.push_back({0, "bottleneck_blocks.1", cin, cin, 0, 0, nres - 1});
+  idx = 0;
+  for (int level = nres - 1; level >= 0; --level) {
+    const int cout = base * c.channel_mult[level];
+    for (int r = 0; r < c.num_res_blocks + 1; ++r) {
+      const int skip = stack.back();
+      stack.pop_back();
+      m->dec.push_back({0, "decoder_blocks." + std::to_string(idx++), skip + cin, cout, c.apply_attention[level] != 0, skip, level});
+      cin = cout;
+    }
+    if (level != 0) m->dec.push_back({2, "decoder_blocks." + std::to_string(idx++), cin, cin, 0, 0, level});
+  }
+  m->final_ch = cin;
+
+  auto add_block_params = [&](const BlockDesc &b) {
+    const std::string &p = b.prefix;
+    if (b.kind == 0) {
+      add_param(m, p + ".normalize_1.weight", {b.cin});
+      add_param(m, p + ".normalize_1.bias", {b.cin});
+      add_param(m, p + ".conv_1.weight", {b.cout, b.cin, 3, 3, 3});
+      add_param(m, p + ".conv_1.bias", {b.cout});
+      add_param(m, p + ".dense_1.weight", {b.cout, tx});
+      add_param(m, p + ".dense_1.bias", {b.cout});
+      add_param(m, p + ".normalize_2.weight", {b.cout});
+      add_param(m, p + ".normalize_2.bias", {b.cout});
+      add_param(m, p + ".conv_2.weight", {b.cout, b.cout, 3, 3, 3});
+      add_param(m, p + ".conv_2.bias", {b.cout});
+      if (b.cin != b.cout) {
+        add_param(m, p + ".match_input.weight", {b.cout, b.cin, 1, 1, 1});
+        add_param(m, p + ".match_input.bias", {b.cout});
+      }
+      if (b.attention) {
+        add_param(m, p + ".attention.group_norm.weight", {b.cout});
+        add_param(m, p + ".attention.group_norm.bias", {b.cout});
+        add_param(m, p + ".attention.mhsa.in_proj_weight", {3 * (int64_t)b.cout, b.cout});
+        add_param(m, p + ".attention.mhsa.in_proj_bias", {3 * (int64_t)b.cout});
+        add_param(m, p + ".attention.mhsa.out_proj.weight", {b.cout, b.cout});
+        add_param(m, p + ".attention.mhsa.out_proj.bias", {b.cout});
+      }
+    } else if (b.kind == 1) {
+      add_param(m, p + ".downsample.weight", {b.cout, b.cin, 3, 3, 3});
+      add_param(m, p + ".downsample.bias", {b.cout});
+    } else {
+      add_param(m, p + ".upsample.1.weight", {b.cout, b.cin, 3, 3, 3});
+      add_param(m, p + ".upsample.1.bias", {b.cout});
+    }
+  };
+  for (auto &b : m->enc) add_block_params(b);
+  for (auto &b : m->bott) add_block_params(b);
+  for (auto &b : m->dec) add_block_params(b);
+  add_param(m, "final.0.weight", {m->final_ch});
+  add_param(m, "final.0.bias", {m->final_ch});
+  add_param(m, "final.2.weight", {c.out_channels, m->final_ch, 3, 3, 3});
+  add_param(m, "final.2.bias", {c.out_channels});
+}
+
+int dev_alloc(cm_model *m, void **p, size_t bytes) {
+  CM_HIP(hipMalloc(p, bytes ? bytes : 4));
+  m->allocs.push_back(*p);
+  return 0;
+}
+
+int upload(cm_model *m, const std::vector<float> &h, float **d) {
+  if (dev_alloc(m, (void **)d, h.size() * sizeof(float))) return 1;
+  CM_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+Act *new_act(cm_model *m, const std::string &name, int C, int Z, int Y, int X, bool stats, int *rc) {
+  auto a = std::make_unique<Act>();
+  a->name = name;
+  a->C = C; a->Z = Z; a->Y = Y; a->X = X;
+  const size_t B = (size_t)m->cfg.max_batch;
+  if (dev_alloc(m, (void **)&a->d, B * a->V() * C * sizeof(float))) { *rc = 1; return nullptr; }
+  if (stats) {
+    a->nslice = std::max(1, std::min(MAX_SLICES, a->V() / 128));
+    if (dev_alloc(m, (void **)&a->part, B * a->nslice * C * 2 * sizeof(float))) { *rc = 1; return nullptr; }
+  }
+  Act *r = a.get();
+  m->acts.push_back(std::move(a));
+  if (!name.empty()) m->act_by_name[name] = r;
+  return r;
+}
+
+const Param &P(const cm_model *m, const std::string &name) { return m->params[m->pindex.at(name)]; }
+
+// ------------------------------------------------------------------------------
+// weight packing: reference [Co][Ci][kH][kW][kL] (or [Co][Ci]) -> fragment order
+//   wfrag[ntile][chunk][step = tap*K8 + j][nb][lane][jj]
+//     = W[co = ntile*TN + nb*32 + (lane&31)][ci = chunk*CK + 8j + 4(lane>>5) + jj][tap]
+// with internal tap (dz,dy,dx) = reference [kH=dy][kW=dx][kL=dz]; zero beyond Co / Ci.
+// One wave-load of a step is 64 lanes x 16 B = 1 KiB contiguous.
+// ------------------------------------------------------------------------------
+std::vector<float> pack_conv_weights(const float *W, int Co, int Ci, int ntaps, int Ci_pad, int CK, int NB) {
+  const int TN = 32 * NB, ntn = (Co + TN - 1) / TN, nch = Ci_pad / CK, K8 = CK / 8, nsteps = ntaps * K8;
+  std::vector<float> out((size_t)ntn * nch * nsteps * NB * 64 * 4, 0.f);
+  size_t o = 0;
+  for (int nt = 0; nt < ntn; ++nt)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int s = 0; s < nsteps; ++s) {
+        const int t = s / K8, j = s % K8;
+        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+        const int tap_ref = (ntaps == 27) ? (dy * 3 + dx) * 3 + dz : 0;
+        for (int nb = 0; nb < NB; ++nb)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int jj = 0; jj < 4; ++jj, ++o) {
+              const int co = nt * TN + nb * 32 + (lane & 31);
+              const int ci = ch * CK + 8 * j + 4 * (lane >> 5) + jj;
+              if (co < Co && ci < Ci) out[o] = W[((size_t)co * Ci + ci) * ntaps + tap_ref];
+            }
+      }
+  return out;
+}
+
+int pick_ck(int C0, int C1) {
+  for (int ck : {32, 16, 8})
+    if (C0 % ck == 0 && C1 % ck == 0) return ck;
+  return 0;
+}
+
+// Tile geometry for one conv at batch B: choose the output box (bs,bz,by,bx) and
+// the per-wave accumulator blocking MB (NB is fixed by the packed weights).
+void pick_tile(Op &op, int B) {
+  cm::ConvArgs &a = op.ca;
+  const int NB = op.NB;
+  const int Zo = a.Zo, Yo = a.Yo, Xo = a.Xo;
+  const int vox = Zo * Yo * Xo;
+  const int max_blk = (NB == 1) ? 8 : (NB == 2 ? 4 : 2);
+  double best = -1;
+  int bbs = 1, bbz = 1, bby = 1, bbx = 1, bMB = 1;
+  const int ntn = (a.Co + 32 * NB - 1) / (32 * NB);
+  for (int bs = 1; bs <= (vox <= 64 ? 4 : 1); ++bs)
+    for (int bz = 1; bz <= Zo; ++bz)
+      for (int by = 1; by <= Yo; ++by)
+        for (int bx = 1; bx <= Xo; ++bx) {
+          const int nbox = bs * bz * by * bx;
+          const int MB = (nbox + 31) / 32;
+          if (MB > max_blk) continue;
+          a.bs = bs; a.bz = bz; a.by = by; a.bx = bx;
+          const size_t lds = cm::conv_lds_bytes(a, MB, NB);
+          if (lds > 64 * 1024) continue;
+          const long ntz = (Zo + bz - 1) / bz, nty = (Yo + by - 1) / by, ntx = (Xo + bx - 1) / bx, nts = (B + bs - 1) / bs;
+          const double tiles = (double)ntz * nty * ntx * nts * ntn;
+          const double util = (double)vox * B * ntn / (tiles * 32.0 * MB);
+          // work per tile in accumulator blocks; balance over 256 CUs
+          const double per_cu = std::ceil(tiles / 256.0);
+          const double balance = tiles / (per_cu * 256.0);
+          // halo overhead (staging) and register-occupancy preference
+          const int pad = a.ntaps == 27 ? 1 : 0;
+          const double hv = (double)bs * ((bz - 1) * a.stride + 1 + 2 * pad) * ((by - 1) * a.stride + 1 + 2 * pad) *
+                            ((bx - 1) * a.stride + 1 + 2 * pad);
+          const double halo = 1.0 / (1.0 + 0.02 * hv / (32.0 * MB));
+          const double occ = (MB * NB <= 4) ? 1.0 : 0.93;
+          const double amort = 1.0 - 0.06 / (MB * NB);  // larger blocks amortise loads/epilogue
+          const double score = util * std::min(1.0, 0.25 + balance) * halo * occ * amort;
+          if (score > best) { best = score; bbs = bs; bbz = bz; bby = by; bbx = bx; bMB = MB; }
+        }
+  a.bs = bbs; a.bz = bbz; a.by = bby; a.bx = bbx;
+  op.MB = bMB;
+  a.ntz = (Zo + bbz - 1) / bbz; a.nty = (Yo + bby - 1) / bby; a.ntx = (Xo + bbx - 1) / bbx;
+  op.tuned_B = B;
+}
+
+struct ConvSpec {
+  const Act *s0;
+  const Act *s1 = nullptr;
+  const float *gn = nullptr;
+  int silu = 0;
+  std::string wname, bname;
+  int ntaps = 27, stride = 1, ups = 0;
+  const float *temb = nullptr;
+  const Act *resid = nullptr;
+  Act *out = nullptr;
+  int Co = 0;
+  int ci_valid = -1;  // valid input channels of the reference weight (first conv: 3 of 8)
+};
+
+int add_conv(cm_model *m, const ConvSpec &s) {
+  Op op;
+  op.kind = OP_CONV;
+  op.cls = s.ntaps == 27 ? K_CONV3 : K_CONV1;
+  cm::ConvArgs &a = op.ca;
+  a.src0 = s.s0->d; a.C0 = s.s0->C;
+  a.src1 = s.s1 ? s.s1->d : nullptr; a.C1 = s.s1 ? s.s1->C : 0;
+  a.gn = s.gn; a.silu = s.silu;
+  a.Zs = s.s0->Z; a.Ys = s.s0->Y; a.Xs = s.s0->X;
+  a.Zo = s.out->Z; a.Yo = s.out->Y; a.Xo = s.out->X;
+  a.ntaps = s.ntaps; a.stride = s.stride; a.ups = s.ups;
+  a.out = s.out->d; a.out_cs = s.out->C; a.Co = s.Co;
+  a.temb = s.temb; a.temb_stride = m->nproj; a.tidx = m->tbuf;
+  a.resid = s.resid ? s.resid->d : nullptr; a.res_cs = s.resid ? s.resid->C : 0;
+  a.CK = pick_ck(a.C0, a.C1);
+  if (!a.CK) return fail("conv %s: channel counts %d/%d not multiples of 8", s.wname.c_str(), a.C0, a.C1);
+  a.nch0 = a.C0 / a.CK; a.nch1 = a.C1 / a.CK;
+  op.NB = s.Co > 32 ? 2 : 1;
+  const Param &w = P(m, s.wname);
+  const Param &b = P(m, s.bname);
+  const int Ci_ref = (int)w.shape[1];
+  const int Ci_pad = a.C0 + a.C1;
+  if (Ci_ref > Ci_pad || (s.ci_valid < 0 && Ci_ref != Ci_pad))
+    return fail("conv %s: weight has %d input channels, sources provide %d", s.wname.c_str(), Ci_ref, Ci_pad);
+  std::vector<float> wf = pack_conv_weights(w.host.data(), (int)w.shape[0], Ci_ref, s.ntaps, Ci_pad, a.CK, op.NB);
+  float *dw = nullptr, *db = nullptr;
+  if (upload(m, wf, &dw)) return 1;
+  const int TN = 32 * op.NB, co_pad = (s.Co + TN - 1) / TN * TN;
+  std::vector<float> bp((size_t)co_pad, 0.f);
+  std::copy(b.host.begin(), b.host.end(), bp.begin());
+  if (upload(m, bp, &db)) return 1;
+  a.wfrag = dw; a.bias = db;
+  op.flops_per_sample = 2.0 * s.out->V() * s.Co * (double)Ci_ref * s.ntaps;
+  m->ops.push_back(op);
+  return 0;
+}
+
+void add_stats(cm_model *m, const Act *a) {
+  Op op;
+  op.kind = OP_STATS; op.cls = K_NORM; op.act = a;
+  m->ops.push_back(op);
+}
+
+int add_gnfin(cm_model *m, const Act *g0, const Act *g1, const std::string &wname, const std::string &bname, float **gn_out) {
+  Op op;
+  op.kind = OP_GNFIN; op.cls = K_NORM; op.g0 = g0; op.g1 = g1;
+  float *dg = nullptr, *db = nullptr;
+  if (upload(m, P(m, wname).host, &dg)) return 1;
+  if (upload(m, P(m, bname).host, &db)) return 1;
+  op.gamma = dg; op.beta = db;
+  const int Ct = g0->C + (g1 ? g1->C : 0);
+  if (dev_alloc(m, (void **)&op.gn_out, (size_t)m->cfg.max_batch * 2 * Ct * sizeof(float))) return 1;
+  *gn_out = op.gn_out;
+  m->ops.push_back(op);
+  return 0;
+}
+
+int build_ops(cm_model *m) {
+  const cm_unet_config &c = m->cfg;
+  const int L = m->L();
+  int rc = 0;
+  // spatial dims per level: conv k3 s2 p1 -> floor((n-1)/2)+1  (layers.py:84)
+  std::vector<int> Zl{L}, Yl{c.rows}, Xl{c.cols};
+  for (int l = 1; l < c.n_levels; ++l) {
+    Zl.push_back((Zl.back() - 1) / 2 + 1);
+    Yl.push_back((Yl.back() - 1) / 2 + 1);
+    Xl.push_back((Xl.back() - 1) / 2 + 1);
+  }
+  for (int l = 1; l < c.n_levels; ++l)
+    if (Zl[l] * 2 != Zl[l - 1] || Yl[l] * 2 != Yl[l - 1] || Xl[l] * 2 != Xl[l - 1])
+      return fail("grid %dx%dx%d is not divisible by 2^%d: the reference's skip concat (unet.py:160) would fail too",
+                  c.rows, c.cols, L, c.n_levels - 1);
+
+  // time-embedding projection table offsets (one slice of nproj per res block)
+  std::map<std::string, int> temb_off;
+  {
+    int off = 0;
+    auto visit = [&](const BlockDesc &b) { if (b.kind == 0) { temb_off[b.prefix] = off; off += b.cout; } };
+    for (auto &b : m->enc) visit(b);
+    for (auto &b : m->bott) visit(b);
+    for (auto &b : m->dec) visit(b);
+    m->nproj = off;
+  }
+  if (dev_alloc(m, (void **)&m->temb_table, (size_t)TIME_ROWS * m->nproj * sizeof(float))) return 1;
+
+  // input / output tensors
+  auto xin = std::make_unique<Act>();
+  xin->name = "input"; xin->C = 8; xin->Z = L; xin->Y = c.rows; xin->X = c.cols;
+  if (dev_alloc(m, (void **)&xin->d, (size_t)c.max_batch * xin->V() * 8 * sizeof(float))) return 1;
+  CM_HIP(hipMemset(xin->d, 0, (size_t)c.max_batch * xin->V() * 8 * sizeof(float)));
+  m->x8 = xin->d; m->x8_act = xin.get();
+  m->acts.push_back(std::move(xin));
+
+  auto res_block = [&](const BlockDesc &b, const Act *x0, const Act *x1, Act **result) -> int {
+    const int l = b.level;
+    const std::string &p = b.prefix;
+    float *gn1 = nullptr, *gn2 = nullptr;
+    if (add_gnfin(m, x0, x1, p + ".normalize_1.weight", p + ".normalize_1.bias", &gn1)) return 1;
+    Act *h1 = new_act(m, p + ".conv_1", b.cout, Zl[l], Yl[l], Xl[l], true, &rc);
+    if (rc) return 1;
+    ConvSpec c1; c1.s0 = x0; c1.s1 = x1; c1.gn = gn1; c1.silu = 1; c1.wname = p + ".conv_1.weight"; c1.bname = p + ".conv_1.bias";
+    c1.temb = m->temb_table + temb_off[p]; c1.out = h1; c1.Co = b.cout;
+    if (add_conv(m, c1)) return 1;
+    add_stats(m, h1);
+    if (add_gnfin(m, h1, nullptr, p + ".normalize_2.weight", p + ".normalize_2.bias", &gn2)) return 1;
+    const Act *resid = x0;
+    if (b.cin != b.cout) {
+      Act *r = new_act(m, p + ".match_input", b.cout, Zl[l], Yl[l], Xl[l], false, &rc);
+      if (rc) return 1;
+      ConvSpec cs; cs.s0 = x0; cs.s1 = x1; cs.ntaps = 1; cs.wname = p + ".match_input.weight"; cs.bname = p + ".match_input.bias";
+      cs.out = r; cs.Co = b.cout;
+      if (add_conv(m, cs)) return 1;
+      resid = r;
+    } else if (x1) {
+      return fail("identity skip with concatenated input is not expressible (block %s)", p.c_str());
+    }
+    Act *h2 = new_act(m, b.attention ? p + ".conv_2+skip" : p, b.cout, Zl[l], Yl[l], Xl[l], true, &rc);
+    if (rc) return 1;
+    ConvSpec c2; c2.s0 = h1; c2.gn = gn2; c2.silu = 1; c2.wname = p + ".conv_2.weight"; c2.bname = p + ".conv_2.bias";
+    c2.resid = resid; c2.out = h2; c2.Co = b.cout;
+    if (add_conv(m, c2)) return 1;
+    add_stats(m, h2);
+    *result = h2;
+    if (b.attention) {
+      const std::string ap = p + ".attention";
+      float *gna = nullptr;
+      if (add_gnfin(m, h2, nullptr, ap + ".group_norm.weight", ap + ".group_norm.bias", &gna)) return 1;
+      Act *qkv = new_act(m, ap + ".qkv", 3 * b.cout, Zl[l], Yl[l], Xl[l], false, &rc);
+      if (rc) return 1;
+      ConvSpec cq; cq.s0 = h2; cq.gn = gna; cq.silu = 0; cq.ntaps = 1; cq.wname = ap + ".mhsa.in_proj_weight"; cq.bname = ap + ".mhsa.in_proj_bias";
+      cq.out = qkv; cq.Co = 3 * b.cout;
+      if (add_conv(m, cq)) return 1;
+      Act *ao = new_act(m, ap + ".core", b.cout, Zl[l], Yl[l], Xl[l], false, &rc);
+      if (rc) return 1;
+      Op at; at.kind = OP_ATTN; at.cls = K_ATTN; at.qkv = qkv->d; at.aout = ao->d; at.S = qkv->V(); at.E = b.cout;
+      if ((size_t)2 * at.S * (at.E / ATTN_HEADS) * 4 > 160 * 1024)
+        return fail("attention with %d tokens exceeds the LDS-resident K/V design", at.S);
+      m->ops.push_back(at);
+      Act *h3 = new_act(m, p, b.cout, Zl[l], Yl[l], Xl[l], true, &rc);
+      if (rc) return 1;
+      ConvSpec co; co.s0 = ao; co.ntaps = 1; co.wname = ap + ".mhsa.out_proj.weight"; co.bname = ap + ".mhsa.out_proj.bias";
+      co.resid = h2; co.out = h3; co.Co = b.cout;
+      if (add_conv(m, co)) return 1;
+      add_stats(m, h3);
+      *result = h3;
+    }
+    return 0;
+  };
+
+  // first conv (unet.py:32,142)
+  Act *h = new_act(m, "first", c.base_channels, Zl[0], Yl[0], Xl[0], true, &rc);
+  if (rc) return 1;
+  {
+    ConvSpec cf; cf.s0 = m->x8_act; cf.wname = "first.weight"; cf.bname = "first.bias"; cf.out = h; cf.Co = c.base_channels; cf.ci_valid = c.in_channels;
+    if (add_conv(m, cf)) return 1;
+    add_stats(m, h);
+  }
+  std::vector<Act *> outs{h};
+  for (auto &b : m->enc) {
+    if (b.kind == 0) {
+      Act *r = nullptr;
+      if (res_block(b, h, nullptr, &r)) return 1;
+      h = r;
+    } else {
+      Act *d = new_act(m, b.prefix, b.cout, Zl[b.level + 1], Yl[b.level + 1], Xl[b.level + 1], true, &rc);
+      if (rc) return 1;
+      ConvSpec cd; cd.s0 = h; cd.stride = 2; cd.wname = b.prefix + ".downsample.weight"; cd.bname = b.prefix + ".downsample.bias"; cd.out = d; cd.Co = b.cout;
+      if (add_conv(m, cd)) return 1;
+      add_stats(m, d);
+      h = d;
+    }
+    outs.push_back(h);
+  }
+  for (auto &b : m->bott) {
+    Act *r = nullptr;
+    if (res_block(b, h, nullptr, &r)) return 1;
+    h = r;
+  }
+  for (auto &b : m->dec) {
+    if (b.kind == 0) {
+      Act *skip = outs.back();
+      outs.pop_back();
+      Act *r = nullptr;
+      if (res_block(b, h, skip, &r)) return 1;  // torch.cat([h, out], dim=1): h first (unet.py:160)
+      h = r;
+    } else {
+      const int l = b.level - 1;
+      Act *u = new_act(m, b.prefix, b.cout, Zl[l], Yl[l], Xl[l], true, &rc);
+      if (rc) return 1;
+      ConvSpec cu; cu.s0 = h; cu.ups = 1; cu.wname = b.prefix + ".upsample.1.weight"; cu.bname = b.prefix + ".upsample.1.bias"; cu.out = u; cu.Co = b.cout;
+      if (add_conv(m, cu)) return 1;
+      add_stats(m, u);
+      h = u;
+    }
+  }
+  // final: GN -> SiLU -> conv (unet.py:118-122,164)
+  {
+    float *gnf = nullptr;
+    if (add_gnfin(m, h, nullptr, "final.0.weight", "final.0.bias", &gnf)) return 1;
+    auto eo = std::make_unique<Act>();
+    eo->name = "final"; eo->C = 8; eo->Z = L; eo->Y = c.rows; eo->X = c.cols;
+    if (dev_alloc(m, (void **)&eo->d, (size_t)c.max_batch * eo->V() * 8 * sizeof(float))) return 1;
+    CM_HIP(hipMemset(eo->d, 0, (size_t)c.max_batch * eo->V() * 8 * sizeof(float)));
+    m->eps_cl = eo->d;
+    Act *eop = eo.get();
+    m->act_by_name["final"] = eop;
+    m->acts.push_back(std::move(eo));
+    ConvSpec cf; cf.s0 = h; cf.gn = gnf; cf.silu = 1; cf.wname = "final.2.weight"; cf.bname = "final.2.bias"; cf.out = eop; cf.Co = c.out_channels;
+    if (add_conv(m, cf)) return 1;
+  }
+  return 0;
+}
+
+// Time-embedding tables for all 1000 rows (embeddings.py:24-30 + layers.py:35,62).
+int build_time_table(cm_model *m) {
+  const cm_unet_config &c = m->cfg;
+  const int te = c.base_channels, tx = c.base_channels * c.time_multiple;
+  std::vector<float> Wd((size_t)m->nproj * tx), bd((size_t)m->nproj);
+  int off = 0;
+  auto visit = [&](const BlockDesc &b) {
+    if (b.kind != 0) return;
+    const Param &w = P(m, b.prefix + ".dense_1.weight");
+    const Param &bb = P(m, b.prefix + ".dense_1.bias");
+    std::copy(w.host.begin(), w.host.end(), Wd.begin() + (size_t)off * tx);
+    std::copy(bb.host.begin(), bb.host.end(), bd.begin() + off);
+    off += b.cout;
+  };
+  for (auto &b : m->enc) visit(b);
+  for (auto &b : m->bott) visit(b);
+  for (auto &b : m->dec) visit(b);
+  float *dT, *dW1, *db1, *dW2, *db2, *dWd, *dbd;
+  if (upload(m, P(m, "time_embeddings.time_blocks.0.weight").host, &dT)) return 1;
+  if (upload(m, P(m, "time_embeddings.time_blocks.1.weight").host, &dW1)) return 1;
+  if (upload(m, P(m, "time_embeddings.time_blocks.1.bias").host, &db1)) return 1;
+  if (upload(m, P(m, "time_embeddings.time_blocks.3.weight").host, &dW2)) return 1;
+  if (upload(m, P(m, "time_embeddings.time_blocks.3.bias").host, &db2)) return 1;
+  if (upload(m, Wd, &dWd)) return 1;
+  if (upload(m, bd, &dbd)) return 1;
+  CM_HIP(cm::launch_time_mlp(dT, dW1, db1, dW2, db2, dWd, dbd, te, tx, m->nproj, TIME_ROWS, nullptr, m->temb_table, m->stream));
+  CM_HIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------
+int run_ops(cm_model *m, int B, hipStream_t st) {
+  for (Op &op : m->ops) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (m->profile) {
+      CM_HIP(hipEventCreate(&e0));
+      CM_HIP(hipEventCreate(&e1));
+      CM_HIP(hipEventRecord(e0, st));
+    }
+    switch (op.kind) {
+      case OP_CONV: {
+        if (op.tuned_B != B) pick_tile(op, B);
+        op.ca.B = B;
+        op.ca.nts = (B + op.ca.bs - 1) / op.ca.bs;
+        CM_HIP(cm::launch_conv(op.ca, op.MB, op.NB, st));
+        break;
+      }
+      case OP_STATS:
+        CM_HIP(cm::launch_chan_stats(op.act->d, B, op.act->V(), op.act->C, op.act->nslice, op.act->part, st));
+        break;
+      case OP_GNFIN:
+        if (op.g1 && (op.g1->nslice != op.g0->nslice || op.g1->V() != op.g0->V()))
+          return fail("concat sources disagree on statistics slicing");
+        CM_HIP(cm::launch_gn_finalize(op.g0->part, op.g0->C, op.g1 ? op.g1->part : nullptr, op.g1 ? op.g1->C : 0,
+                                      op.g0->nslice, op.g0->V(), op.gamma, op.beta, GN_GROUPS, GN_EPS, op.gn_out, B, st));
+        break;
+      case OP_ATTN:
+        CM_HIP(cm::launch_attn_core(op.qkv, op.aout, B, op.S, op.E, ATTN_HEADS, st));
+        break;
+    }
+    if (m->profile) {
+      CM_HIP(hipEventRecord(e1, st));
+      m->prof_events.push_back({op.cls, {e0, e1}});
+    }
+  }
+  return 0;
+}
+
+int prof_begin(cm_model *m) {
+  if (!m->profile) return 0;
+  for (int i = 0; i < K_NCLASS; ++i) { m->prof_ms[i] = 0; m->prof_n[i] = 0; }
+  return 0;
+}
+
+int prof_collect(cm_model *m, hipStream_t st) {
+  if (!m->profile) return 0;
+  CM_HIP(hipStreamSynchronize(st));
+  for (auto &pe : m->prof_events) {
+    float ms = 0;
+    CM_HIP(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
+    m->prof_ms[pe.first] += ms;
+    m->prof_n[pe.first] += 1;
+    hipEventDestroy(pe.second.first);
+    hipEventDestroy(pe.second.second);
+  }
+  m->prof_events.clear();
+  return 0;
+}
+
+struct DevGuard {
+  int prev = -1;
+  explicit DevGuard(int dev) {
+    hipGetDevice(&prev);
+    if (prev != dev) hipSetDevice(dev);
+  }
+};
+
+int check_ready(cm_model *m, int B) {
+  if (!m) return fail("null model handle");
+  if (!m->finalized) return fail("cm_model_finalize has not been called");
+  if (B < 1 || B > m->cfg.max_batch) return fail("batch %d outside [1, max_batch=%d]", B, m->cfg.max_batch);
+  return 0;
+}
+
+// torch.linspace / cumprod semantics of forward.py:15-27 (see oracle/unet_numpy.py:
+// fp32 step, symmetric fill, fused multiply-add; cumprod accumulated in double).
+void build_schedule(cm_schedule *s, int T, float scale, float beta_start, float beta_end) {
+  s->T = T;
+  for (auto &t : s->tab) t.assign((size_t)T, 0.f);
+  const float start = (float)((double)scale * (double)beta_start), end = (float)((double)scale * (double)beta_end);
+  const double step = (double)(float)(((double)end - (double)start) / (double)(T - 1));
+  double acc = 1.0;
+  for (int i = 0; i < T; ++i) {
+    const double b = (i < T / 2) ? (double)start + step * i : (double)end - step * (T - 1 - i);
+    const float beta = (float)b;
+    const float alpha = 1.0f - beta;
+    acc *= (double)alpha;
+    const float abar = (float)acc;
+    s->tab[CM_TAB_BETA][i] = beta;
+    s->tab[CM_TAB_ALPHA][i] = alpha;
+    s->tab[CM_TAB_ALPHA_BAR][i] = abar;
+    s->tab[CM_TAB_SQRT_ALPHA_BAR][i] = sqrtf(abar);
+    s->tab[CM_TAB_ONE_BY_SQRT_ALPHA][i] = 1.0f / sqrtf(alpha);
+    s->tab[CM_TAB_SQRT_ONE_MINUS_ALPHA_BAR][i] = sqrtf(1.0f - abar);
+  }
+}
+
+std::vector<int> visit_order(const cm_schedule *s, const cm_sample_opts *o) {
+  std::vector<int> v;
+  if (o->sampler == CM_SAMPLER_DDIM) {
+    const int d = std::max(1, o->ddim_divider);
+    std::vector<int> taus;
+    for (int t = 0; t < s->T - 1; t += d) taus.push_back(t);  // np.arange(0, T-1, divider), ddpm.py:326
+    v.assign(taus.rbegin(), taus.rend());
+  } else {
+    for (int t = s->T - 1; t >= 0; --t) v.push_back(t);       // reversed(range(T)), ddpm.py:214
+  }
+  if (o->first_steps > 0 && (size_t)o->first_steps < v.size()) v.resize((size_t)o->first_steps);
+  return v;
+}
+
+}  // namespace
+
+// ================================================================================
+// C ABI
+// ================================================================================
+extern "C" {
+
+const char *cm_last_error(void) { return g_err.c_str(); }
+int cm_abi_version(void) { return CM_ABI_VERSION; }
+
+int cm_device_count(int *count) {
+  if (!count) return fail("null argument");
+  CM_HIP(hipGetDeviceCount(count));
+  return 0;
+}
+
+int cm_malloc(int device, void **d_ptr, size_t bytes) {
+  if (!d_ptr) return fail("null argument");
+  DevGuard g(device);
+  CM_HIP(hipMalloc(d_ptr, bytes ? bytes : 4));
+  return 0;
+}
+int cm_free(int device, void *d_ptr) {
+  DevGuard g(device);
+  CM_HIP(hipFree(d_ptr));
+  return 0;
+}
+int cm_memcpy_h2d(int device, void *d_dst, const void *h_src, size_t bytes) {
+  DevGuard g(device);
+  CM_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+int cm_memcpy_d2h(int device, void *h_dst, const void *d_src, size_t bytes) {
+  DevGuard g(device);
+  CM_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+int cm_memcpy_d2d(int device, void *d_dst, const void *d_src, size_t bytes) {
+  DevGuard g(device);
+  CM_HIP(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+  return 0;
+}
+int cm_device_synchronize(int device) {
+  DevGuard g(device);
+  CM_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+int cm_model_create(const cm_unet_config *cfg, cm_model **out) {
+  if (!cfg || !out) return fail("null argument");
+  if (cfg->n_levels < 1 || cfg->n_levels > CM_MAX_LEVELS) return fail("n_levels %d out of range", cfg->n_levels);
+  if (cfg->base_channels < 8 || cfg->base_channels % 8) return fail("base_channels must be a positive multiple of 8");
+  if (cfg->in_channels < 1 || cfg->in_channels > 8 || cfg->out_channels < 1 || cfg->out_channels > 8)
+    return fail("in/out channels must be in [1,8]");
+  if (cfg->max_batch < 1) return fail("max_batch must be >= 1");
+  if (cfg->num_res_blocks < 1) return fail("num_res_blocks must be >= 1");
+  if ((cfg->base_channels / 2) < 2) return fail("base_channels too small for the sinusoidal table");
+  int ndev = 0;
+  CM_HIP(hipGetDeviceCount(&ndev));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail("device %d not available (%d devices)", cfg->device, ndev);
+  auto m = std::make_unique<cm_model>();
+  m->cfg = *cfg;
+  m->device = cfg->device;
+  for (int l = 0; l < cfg->n_levels; ++l)
+    if (cfg->channel_mult[l] < 1 || (cfg->base_channels * cfg->channel_mult[l]) % (GN_GROUPS) != 0)
+      return fail("channel_mult[%d] invalid", l);
+  build_plan(m.get());
+  DevGuard g(m->device);
+  CM_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  *out = m.release();
+  return 0;
+}
+
+int cm_model_destroy(cm_model *m) {
+  if (!m) return 0;
+  DevGuard g(m->device);
+  hipDeviceSynchronize();
+  for (void *p : m->allocs) hipFree(p);
+  if (m->stream) hipStreamDestroy(m->stream);
+  delete m;
+  return 0;
+}
+
+int cm_model_num_params(const cm_model *m, int32_t *count) {
+  if (!m || !count) return fail("null argument");
+  *count = (int32_t)m->params.size();
+  return 0;
+}
+
+int cm_model_param_info(const cm_model *m, int32_t index, const char **name, int64_t shape[5], int32_t *ndim) {
+  if (!m || index < 0 || index >= (int)m->params.size()) return fail("parameter index out of range");
+  const Param &p = m->params[index];
+  if (name) *name = p.name.c_str();
+  if (ndim) *ndim = (int32_t)p.shape.size();
+  if (shape)
+    for (size_t i = 0; i < 5; ++i) shape[i] = i < p.shape.size() ? p.shape[i] : 1;
+  return 0;
+}
+
+int cm_model_set_param(cm_model *m, const char *name, const float *h_data, int64_t numel) {
+  if (!m || !name || !h_data) return fail("null argument");
+  auto it = m->pindex.find(name);
+  if (it == m->pindex.end()) return fail("unexpected key in state_dict: %s", name);
+  Param &p = m->params[it->second];
+  if (numel != p.numel()) return fail("size mismatch for %s: got %lld elements, expected %lld", name, (long long)numel, (long long)p.numel());
+  if (m->finalized) return fail("model already finalized; create a new handle to load other weights");
+  std::memcpy(p.host.data(), h_data, (size_t)numel * sizeof(float));
+  p.set = true;
+  return 0;
+}
+
+int cm_model_get_param(const cm_model *m, const char *name, float *h_data, int64_t numel) {
+  if (!m || !name || !h_data) return fail("null argument");
+  auto it = m->pindex.find(name);
+  if (it == m->pindex.end()) return fail("unknown parameter %s", name);
+  const Param &p = m->params[it->second];
+  if (numel != p.numel()) return fail("size mismatch for %s", name);
+  std::memcpy(h_data, p.host.data(), (size_t)numel * sizeof(float));
+  return 0;
+}
+
+int cm_model_finalize(cm_model *m) {
+  if (!m) return fail("null model handle");
+  if (m->finalized) return 0;
+  for (auto &p : m->params)
+    if (!p.set) return fail("missing key in state_dict: %s", p.name.c_str());
+  DevGuard g(m->device);
+  const cm_unet_config &c = m->cfg;
+  const size_t B = (size_t)c.max_batch;
+  if (dev_alloc(m, (void **)&m->tbuf, B * sizeof(long long))) return 1;
+  CM_HIP(hipMemset(m->tbuf, 0, B * sizeof(long long)));
+  if (build_ops(m)) return 1;
+  if (build_time_table(m)) return 1;
+  const size_t per = (size_t)m->per_sample();
+  const size_t per_past = (size_t)c.in_channels * c.rows * c.cols * c.past_len;
+  if (dev_alloc(m, (void **)&m->xstate, B * per * sizeof(float))) return 1;
+  if (dev_alloc(m, (void **)&m->stage_fut, B * per * sizeof(float))) return 1;
+  if (dev_alloc(m, (void **)&m->stage_out, B * per * sizeof(float))) return 1;
+  if (dev_alloc(m, (void **)&m->stage_past, B * per_past * sizeof(float))) return 1;
+  CM_HIP(hipDeviceSynchronize());
+  m->finalized = true;
+  return 0;
+}
+
+int cm_unet_forward(cm_model *m, const float *d_future, const int64_t *d_t, const float *d_past, float *d_out,
+                    int32_t B, void *stream) {
+  if (check_ready(m, B)) return 1;
+  if (!d_future || !d_t || !d_past || !d_out) return fail("null tensor argument");
+  DevGuard g(m->device);
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  const cm_unet_config &c = m->cfg;
+  prof_begin(m);
+  CM_HIP(hipMemcpyAsync(m->tbuf, d_t, (size_t)B * sizeof(long long), hipMemcpyDeviceToDevice, st));
+  CM_HIP(cm::launch_assemble_input(d_past, d_future, m->x8, B, c.in_channels, c.rows, c.cols, c.past_len, c.future_len, 3, st));
+  if (run_ops(m, B, st)) return 1;
+  CM_HIP(cm::launch_extract_output(m->eps_cl, 8, d_out, B, c.out_channels, c.rows, c.cols, c.past_len, c.future_len, st));
+  return prof_collect(m, st);
+}
+
+int cm_unet_forward_host(cm_model *m, const float *h_future, const int64_t *h_t, const float *h_past, float *h_out,
+                         int32_t B) {
+  if (check_ready(m, B)) return 1;
+  if (!h_future || !h_t || !h_past || !h_out) return fail("null tensor argument");
+  DevGuard g(m->device);
+  const cm_unet_config &c = m->cfg;
+  for (int i = 0; i < B; ++i)
+    if (h_t[i] < 0 || h_t[i] >= TIME_ROWS) return fail("timestep %lld outside [0,%d)", (long long)h_t[i], TIME_ROWS);
+  const size_t per = (size_t)m->per_sample();
+  const size_t per_past = (size_t)c.in_channels * c.rows * c.cols * c.past_len;
+  CM_HIP(hipMemcpy(m->stage_fut, h_future, B * per * sizeof(float), hipMemcpyHostToDevice));
+  CM_HIP(hipMemcpy(m->stage_past, h_past, B * per_past * sizeof(float), hipMemcpyHostToDevice));
+  long long *dt = nullptr;
+  CM_HIP(hipMalloc((void **)&dt, (size_t)B * sizeof(long long)));
+  hipError_t e = hipMemcpy(dt, h_t, (size_t)B * sizeof(long long), hipMemcpyHostToDevice);
+  int rc = (e != hipSuccess) ? fail("hipMemcpy t failed") : cm_unet_forward(m, m->stage_fut, (const int64_t *)dt, m->stage_past, m->stage_out, B, nullptr);
+  if (!rc) {
+    e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) rc = fail("forward failed: %s", hipGetErrorString(e));
+  }
+  hipFree(dt);
+  if (rc) return rc;
+  CM_HIP(hipMemcpy(h_out, m->stage_out, B * per * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int cm_debug_activation(cm_model *m, const char *name, float *h_out, int64_t capacity, int64_t shape[5]) {
+  if (!m || !name || !h_out) return fail("null argument");
+  if (!m->finalized) return fail("model not finalized");
+  auto it = m->act_by_name.find(name);
+  if (it == m->act_by_name.end()) return fail("no activation named %s", name);
+  const Act *a = it->second;
+  DevGuard g(m->device);
+  const int B = m->cfg.max_batch;
+  const int C = a->C;
+  const int64_t n = (int64_t)B * C * a->V();
+  if (capacity < n) return fail("capacity %lld < %lld", (long long)capacity, (long long)n);
+  float *tmp = nullptr;
+  CM_HIP(hipMalloc((void **)&tmp, (size_t)n * sizeof(float)));
+  hipError_t e = cm::launch_cl_to_ref(a->d, a->C, tmp, B, C, a->Z, a->Y, a->X, m->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+  if (e == hipSuccess) e = hipMemcpy(h_out, tmp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+  hipFree(tmp);
+  if (e != hipSuccess) return fail("debug copy failed: %s", hipGetErrorString(e));
+  if (shape) { shape[0] = B; shape[1] = C; shape[2] = a->Y; shape[3] = a->X; shape[4] = a->Z; }
+  return 0;
+}
+
+// ---- schedule -----------------------------------------------------------------
+int cm_schedule_create(int32_t timesteps, float scale, float beta_start, float beta_end, int32_t device, cm_schedule **out) {
+  if (!out) return fail("null argument");
+  if (timesteps < 2) return fail("timesteps must be >= 2");
+  auto s = std::make_unique<cm_schedule>();
+  s->device = device;
+  build_schedule(s.get(), timesteps, scale, beta_start, beta_end);
+  if (device >= 0) {
+    DevGuard g(device);
+    CM_HIP(hipMalloc((void **)&s->d_sab, (size_t)timesteps * sizeof(float)));
+    CM_HIP(hipMalloc((void **)&s->d_s1m, (size_t)timesteps * sizeof(float)));
+    CM_HIP(hipMemcpy(s->d_sab, s->tab[CM_TAB_SQRT_ALPHA_BAR].data(), (size_t)timesteps * sizeof(float), hipMemcpyHostToDevice));
+    CM_HIP(hipMemcpy(s->d_s1m, s->tab[CM_TAB_SQRT_ONE_MINUS_ALPHA_BAR].data(), (size_t)timesteps * sizeof(float), hipMemcpyHostToDevice));
+  }
+  *out = s.release();
+  return 0;
+}
+
+int cm_schedule_destroy(cm_schedule *s) {
+  if (!s) return 0;
+  if (s->device >= 0) {
+    DevGuard g(s->device);
+    if (s->d_sab) hipFree(s->d_sab);
+    if (s->d_s1m) hipFree(s->d_s1m);
+  }
+  delete s;
+  return 0;
+}
+
+int cm_schedule_table(const cm_schedule *s, int32_t which, float *h_out, int32_t capacity) {
+  if (!s || !h_out) return fail("null argument");
+  if (which < 0 || which > 5) return fail("table id %d out of range", which);
+  if (capacity < s->T) return fail("capacity %d < timesteps %d", capacity, s->T);
+  std::memcpy(h_out, s->tab[which].data(), (size_t)s->T * sizeof(float));
+  return 0;
+}
+
+int cm_q_sample(const cm_schedule *s, const float *d_x0, const int64_t *d_t, const float *d_eps, float *d_xt, int32_t B,
+                int64_t per_sample, void *stream) {
+  if (!s || !d_x0 || !d_t || !d_eps || !d_xt) return fail("null argument");
+  if (s->device < 0) return fail("schedule was created host-only (device < 0)");
+  DevGuard g(s->device);
+  CM_HIP(cm::launch_q_sample(d_x0, (const long long *)d_t, d_eps, s->d_sab, s->d_s1m, d_xt, B, per_sample, (hipStream_t)stream));
+  return 0;
+}
+
+static void ddpm_coeffs(const cm_schedule *s, int t, float *cx, float *ce, float *cn) {
+  const float beta = s->tab[CM_TAB_BETA][t];
+  const float c1 = s->tab[CM_TAB_ONE_BY_SQRT_ALPHA][t];
+  const float s1m = s->tab[CM_TAB_SQRT_ONE_MINUS_ALPHA_BAR][t];
+  *cx = c1;
+  *ce = -c1 * (beta / s1m);
+  *cn = sqrtf(beta);
+}
+
+int cm_ddpm_step(const cm_schedule *s, const float *d_eps, float *d_x, int32_t t, const float *d_noise, uint64_t seed,
+                 int64_t sample_id_base, int32_t B, int64_t per_sample, void *stream) {
+  if (!s || !d_eps || !d_x) return fail("null argument");
+  if (t < 0 || t >= s->T) return fail("timestep %d outside [0,%d)", t, s->T);
+  if (s->device < 0) return fail("schedule was created host-only (device < 0)");
+  DevGuard g(s->device);
+  // eps arrives in reference layout here: express it as a degenerate channels-last
+  // tensor with C=1 (cs = 1, P = 0, H = W = 1, F = per_sample).
+  cm::StepArgs a{};
+  a.x = d_x; a.eps_cl = d_eps; a.cs = 1; a.x8 = nullptr; a.noise = d_noise; a.hist = nullptr;
+  a.B = B; a.C = 1; a.H = 1; a.W = 1; a.P = 0; a.F = (int)per_sample;
+  ddpm_coeffs(s, t, &a.c_x, &a.c_eps, &a.c_noise);
+  a.guid = 0.f; a.seed = seed; a.sample_id_base = sample_id_base; a.step = t; a.draw = t > 0;
+  CM_HIP(cm::launch_sampler_step(a, (hipStream_t)stream));
+  return 0;
+}
+
+int cm_sample_num_steps(const cm_schedule *s, const cm_sample_opts *opts, int32_t *nsteps) {
+  if (!s || !opts || !nsteps) return fail("null argument");
+  *nsteps = (int32_t)visit_order(s, opts).size();
+  return 0;
+}
+
+int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const float *d_xT, const float *d_noise,
+                   const cm_sample_opts *opts, float *d_out, float *d_history, int32_t B, void *stream) {
+  if (check_ready(m, B)) return 1;
+  if (!s || !d_past || !opts || !d_out) return fail("null argument");
+  if (s->T > TIME_ROWS) return fail("timesteps %d exceed the %d-row time-embedding table (embeddings.py:7)", s->T, TIME_ROWS);
+  DevGuard g(m->device);
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  const cm_unet_config &c = m->cfg;
+  const size_t per = (size_t)m->per_sample();
+  const std::vector<int> order = visit_order(s, opts);
+  prof_begin(m);
+  // x_T: injected or drawn on device (ddpm.py:211,242)
+  if (d_xT) CM_HIP(hipMemcpyAsync(m->xstate, d_xT, B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
+  else CM_HIP(cm::launch_randn(m->xstate, B, (long long)per, opts->seed, opts->sample_id_base, 0x7fffffff, st));
+  if (d_history) CM_HIP(hipMemcpyAsync(d_history, m->xstate, B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
+  CM_HIP(cm::launch_assemble_input(d_past, m->xstate, m->x8, B, c.in_channels, c.rows, c.cols, c.past_len, c.future_len, 3, st));
+
+  // DDIM carries the schedule values of the previously visited step (ddpm.py:245-248)
+  const int last = s->T - 1;
+  float beta_t = s->tab[CM_TAB_BETA][last], sab_t = s->tab[CM_TAB_SQRT_ALPHA_BAR][last],
+        s1m_t = s->tab[CM_TAB_SQRT_ONE_MINUS_ALPHA_BAR][last];
+  for (size_t k = 0; k < order.size(); ++k) {
+    const int t = order[k];
+    CM_HIP(cm::launch_fill_t(m->tbuf, B, t, st));
+    if (run_ops(m, B, st)) return 1;
+    cm::StepArgs a{};
+    a.x = m->xstate; a.eps_cl = m->eps_cl; a.cs = 8; a.x8 = m->x8;
+    a.B = B; a.C = c.in_channels; a.H = c.rows; a.W = c.cols; a.P = c.past_len; a.F = c.future_len;
+    a.seed = opts->seed; a.sample_id_base = opts->sample_id_base; a.step = t;
+    a.hist = d_history ? d_history + (k + 1) * B * per : nullptr;
+    a.noise = d_noise ? d_noise + k * B * per : nullptr;
+    if (opts->sampler == CM_SAMPLER_DDIM) {
+      const float sab_p = s->tab[CM_TAB_SQRT_ALPHA_BAR][t], s1m_p = s->tab[CM_TAB_SQRT_ONE_MINUS_ALPHA_BAR][t];
+      const float sig = opts->ddim_sigma;
+      a.c_x = sab_p / sab_t;
+      a.c_eps = sqrtf(1.0f - sab_p * sab_p - sig * sig) - sab_p * s1m_t / sab_t;
+      a.c_noise = sig;
+      a.draw = 1;                                                  // noise on every step (ddpm.py:264)
+      a.guid = opts->guidance == CM_GUIDANCE_SPARSITY ? opts->lambda_guidance * sqrtf(beta_t) : 0.f;  // ddpm.py:270
+      beta_t = s->tab[CM_TAB_BETA][t]; sab_t = sab_p; s1m_t = s1m_p;
+    } else {
+      ddpm_coeffs(s, t, &a.c_x, &a.c_eps, &a.c_noise);
+      a.draw = t > 0;                                              // ddpm.py:27
+      a.guid = opts->guidance == CM_GUIDANCE_SPARSITY ? opts->lambda_guidance * sqrtf(s->tab[CM_TAB_BETA][t]) : 0.f;
+    }
+    if (a.draw == 0) a.noise = nullptr;
+    CM_HIP(cm::launch_sampler_step(a, st));
+  }
+  CM_HIP(hipMemcpyAsync(d_out, m->xstate, B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return prof_collect(m, st);
+}
+
+int cm_sample_loop_host(cm_model *m, const cm_schedule *s, const float *h_past, const float *h_xT, const float *h_noise,
+                        const cm_sample_opts *opts, float *h_out, float *h_history, int32_t B) {
+  if (check_ready(m, B)) return 1;
+  if (!s || !h_past || !opts || !h_out) return fail("null argument");
+  DevGuard g(m->device);
+  const cm_unet_config &c = m->cfg;
+  const size_t per = (size_t)m->per_sample();
+  const size_t per_past = (size_t)c.in_channels * c.rows * c.cols * c.past_len;
+  const size_t nsteps = visit_order(s, opts).size();
+  CM_HIP(hipMemcpy(m->stage_past, h_past, B * per_past * sizeof(float), hipMemcpyHostToDevice));
+  if (h_xT) CM_HIP(hipMemcpy(m->stage_fut, h_xT, B * per * sizeof(float), hipMemcpyHostToDevice));
+  float *dn = nullptr, *dh = nullptr;
+  if (h_noise) {
+    CM_HIP(hipMalloc((void **)&dn, nsteps * B * per * sizeof(float)));
+    hipError_t e = hipMemcpy(dn, h_noise, nsteps * B * per * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(dn); return fail("noise upload failed: %s", hipGetErrorString(e)); }
+  }
+  if (h_history) {
+    hipError_t e = hipMalloc((void **)&dh, (nsteps + 1) * B * per * sizeof(float));
+    if (e != hipSuccess) { if (dn) hipFree(dn); return fail("history alloc failed: %s", hipGetErrorString(e)); }
+  }
+  int rc = cm_sample_loop(m, s, m->stage_past, h_xT ? m->stage_fut : nullptr, dn, opts, m->stage_out, dh, B, nullptr);
+  if (!rc) {
+    hipError_t e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) rc = fail("sampling loop failed: %s", hipGetErrorString(e));
+  }
+  if (!rc) {
+    hipError_t e = hipMemcpy(h_out, m->stage_out, B * per * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && h_history) e = hipMemcpy(h_history, dh, (nsteps + 1) * B * per * sizeof(float), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail("result download failed: %s", hipGetErrorString(e));
+  }
+  if (dn) hipFree(dn);
+  if (dh) hipFree(dh);
+  return rc;
+}
+
+int cm_profile_enable(cm_model *m, int32_t on) {
+  if (!m) return fail("null model handle");
+  m->profile = on != 0;
+  return 0;
+}
+
+int cm_profile_read(cm_model *m, float ms[8], int64_t launches[8]) {
+  if (!m || !ms || !launches) return fail("null argument");
+  for (int i = 0; i < 8; ++i) { ms[i] = m->prof_ms[i]; launches[i] = m->prof_n[i]; }
+  return 0;
+}
+
+int cm_model_cost(const cm_model *m, int32_t B, double *flops, double *bytes) {
+  if (!m || !m->finalized) return fail("model not finalized");
+  double f = 0, by = 0;
+  for (const Op &op : m->ops) {
+    if (op.kind == OP_CONV) {
+      f += op.flops_per_sample * B;
+      const cm::ConvArgs &a = op.ca;
+      const double vin = (double)a.Zs * a.Ys * a.Xs, vout = (double)a.Zo * a.Yo * a.Xo;
+      by += 4.0 * B * (vin * (a.C0 + a.C1) + vout * a.Co);
+    } else if (op.kind == OP_ATTN) {
+      f += 4.0 * op.S * (double)op.S * op.E * B;
+    }
+  }
+  double wbytes = 0;
+  for (const Param &p : m->params) wbytes += 4.0 * p.numel();
+  if (flops) *flops = f;
+  if (bytes) *bytes = by + wbytes;
+  return 0;
+}
+
+}  // extern "C"

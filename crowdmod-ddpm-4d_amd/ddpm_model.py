@@ -1,0 +1,150 @@
+"""Host-side mirror of the reference's `DDPM_model` driver for the DDPM-UNet path
+(/root/reference/models/diffusion/ddpm.py:40-108,206-282).
+
+`_generate_ddpm` / `_generate_ddim` keep the reference signatures and return
+values -- `(x0, [x_T, ..., x0])` -- but the whole reverse loop runs on the device
+behind ONE native call (cm_sample_loop): T sequential UNet forwards + sampler
+updates, no host round trip per step.
+
+Noise: by default x_T and z_t come from the device Philox stream keyed by
+(seed, global sample index, step) -- results do not depend on how the batch is
+sharded over GPUs.  `x_T=` / `noise=` inject explicit tensors (parity tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import config as cfgmod
+from . import native
+from .diffusion import DDPM
+from .unet import UNet, _is_torch
+
+
+class DDPM_model:
+    def __init__(self, cfg, arch, mprops_count, output_dir=None, from_fixed_past=False, *, device: int = 0,
+                 seed: int = 42):
+        self.cfg = cfg
+        self.arch = arch
+        self.mprops_count = int(mprops_count)
+        self.output_dir = output_dir
+        self.from_fixed_past = from_fixed_past
+        self.device = int(device)
+        self.seed = int(seed)
+        self.denoiser_cfg = self._get_denoiser_cfg()
+        self.res = cfgmod.resolve(cfg, arch)
+        self.denoiser = self._get_denoiser()
+        self._sample_calls = 0
+
+    def _get_denoiser_cfg(self):
+        """ddpm.py:65-72; tolerant of the older schema generations."""
+        gen_key, back_key = self.arch.upper().split("-")
+        gen = self.cfg.MODEL.get(gen_key) if "MODEL" in self.cfg else None
+        if gen is not None and back_key in gen:
+            return gen[back_key]
+        return gen if gen is not None else self.cfg.get("MODEL")
+
+    def _get_denoiser(self):
+        """ddpm.py:74-108."""
+        if self.arch != "DDPM-UNet":
+            raise ValueError(f"Unknown Architecture {self.arch}")
+        r = self.res
+        return UNet(input_channels=self.mprops_count, output_channels=self.mprops_count,
+                    num_res_blocks=r.num_res_blocks, base_channels=r.base_ch,
+                    base_channels_multiples=r.base_ch_mult, apply_attention=r.apply_attention,
+                    dropout_rate=r.dropout_rate, time_multiple=r.time_emb_mult, condition=r.condition,
+                    device=self.device, max_batch=max(1, r.batch_size), seed=self.seed)
+
+    # ------------------------------------------------------------------------------
+    def _opts(self, sampler: int, divider: int = 1, first_steps: int = 0, sample_id_base: int = 0,
+              seed: Optional[int] = None) -> native.cm_sample_opts:
+        r = self.res
+        o = native.cm_sample_opts()
+        o.sampler = sampler
+        o.guidance = native.GUIDANCE_SPARSITY if r.guidance == "Sparsity" else native.GUIDANCE_NONE  # case-sensitive, ddpm.py:223
+        if r.guidance == "mass_preservation":
+            raise NotImplementedError("mass_preservation guidance is out of scope (O(N^2) finite differences per step)")
+        o.lambda_guidance = float(r.lambda_guidance)
+        o.ddim_sigma = float(r.sigma)
+        o.ddim_divider = int(divider)
+        o.first_steps = int(first_steps)
+        o.seed = int(self.seed if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        o.sample_id_base = int(sample_id_base)
+        o.use_graph = 0
+        return o
+
+    def _run_loop(self, past, sampler_obj: DDPM, nsamples: int, opts: native.cm_sample_opts, history: bool,
+                  x_T=None, noise=None):
+        r = self.res
+        L = native.lib()
+        B = int(nsamples)
+        if int(past.shape[0]) != B:
+            raise ValueError(f"past has batch {past.shape[0]}, nsamples={B}")
+        C_, H, W, P, F = self.mprops_count, r.rows, r.cols, r.past_len, r.future_len
+        h = self.denoiser.eval().ensure(H, W, P, F, B)
+        ns = C.c_int32()
+        native.check(L.cm_sample_num_steps(sampler_obj._handle, C.byref(opts), C.byref(ns)))
+        nsteps = ns.value
+        shape = (B, C_, H, W, F)
+        if _is_torch(past):
+            import torch
+            dev = past.device
+            pst = past.contiguous().float()
+            out = torch.empty(shape, device=dev, dtype=torch.float32)
+            hist = torch.empty((nsteps + 1,) + shape, device=dev, dtype=torch.float32) if history else None
+            xt = x_T.contiguous().float() if x_T is not None else None
+            nz = noise.contiguous().float() if noise is not None else None
+            st = torch.cuda.current_stream(dev).cuda_stream
+            native.check(L.cm_sample_loop(h, sampler_obj._handle, pst.data_ptr(), xt.data_ptr() if xt is not None else None,
+                                          nz.data_ptr() if nz is not None else None, C.byref(opts), out.data_ptr(),
+                                          hist.data_ptr() if hist is not None else None, B, st))
+            if history:
+                return out, [hist[i] for i in range(nsteps + 1)]
+            return out, None
+        pst = np.ascontiguousarray(past, dtype=np.float32)
+        out = np.empty(shape, dtype=np.float32)
+        hist = np.empty((nsteps + 1,) + shape, dtype=np.float32) if history else None
+        xt = np.ascontiguousarray(x_T, dtype=np.float32) if x_T is not None else None
+        nz = np.ascontiguousarray(noise, dtype=np.float32) if noise is not None else None
+        if nz is not None and nz.shape[0] < (nsteps - (1 if opts.sampler == native.SAMPLER_DDPM else 0)):
+            raise ValueError("noise tensor has too few steps")
+        if nz is not None and nz.shape[0] < nsteps:  # DDPM: the t=0 row is never read; pad for the upload
+            nz = np.concatenate([nz, np.zeros((nsteps - nz.shape[0],) + nz.shape[1:], np.float32)])
+        native.check(L.cm_sample_loop_host(h, sampler_obj._handle, pst.ctypes.data,
+                                           xt.ctypes.data if xt is not None else None,
+                                           nz.ctypes.data if nz is not None else None, C.byref(opts), out.ctypes.data,
+                                           hist.ctypes.data if hist is not None else None, B))
+        if history:
+            return out, [hist[i] for i in range(nsteps + 1)]
+        return out, None
+
+    def _generate_ddpm(self, past, backward_sampler: DDPM, nsamples, history=False, *, x_T=None, noise=None,
+                       sample_id_base: int = 0, first_steps: int = 0):
+        """ddpm.py:206-236.  Returns (x0, [x_T, (x after every step if history), x0])."""
+        opts = self._opts(native.SAMPLER_DDPM, first_steps=first_steps, sample_id_base=sample_id_base,
+                          seed=self.seed + 7919 * self._sample_calls)
+        self._sample_calls += 1
+        x, hist = self._run_loop(past, backward_sampler, nsamples, opts, bool(history), x_T, noise)
+        if history:
+            return x, hist
+        # without history the device-drawn x_T is not copied back (None stands in for it)
+        return x, [x_T, x]
+
+    def _generate_ddim(self, past, taus: Sequence[int], backward_sampler: DDPM, nsamples, history=False, *, x_T=None,
+                       noise=None, sample_id_base: int = 0):
+        """ddpm.py:238-282.  `taus` must be np.arange(0, T-1, divider) as built at ddpm.py:326."""
+        taus = np.asarray(taus)
+        divider = int(taus[1] - taus[0]) if len(taus) > 1 else max(1, backward_sampler.timesteps)
+        expect = np.arange(0, backward_sampler.timesteps - 1, divider)
+        if len(taus) != len(expect) or np.any(taus != expect):
+            raise ValueError("taus must equal np.arange(0, timesteps-1, divider)")
+        opts = self._opts(native.SAMPLER_DDIM, divider=divider, sample_id_base=sample_id_base,
+                          seed=self.seed + 7919 * self._sample_calls)
+        self._sample_calls += 1
+        x, hist = self._run_loop(past, backward_sampler, nsamples, opts, bool(history), x_T, noise)
+        if history:
+            return x, hist
+        # without history the device-drawn x_T is not copied back (None stands in for it)
+        return x, [x_T, x]

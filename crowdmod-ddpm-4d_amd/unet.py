@@ -1,0 +1,184 @@
+"""Host-side mirror of the reference denoiser interface.
+
+`UNet` has the constructor signature and call convention of
+/root/reference/models/backbones/unet.py:7-25,124 --
+`denoiser(future[B,C,H,W,F], t[B] int64, past[B,C,H,W,P]) -> [B,C,H,W,F]` -- and the
+`nn.Module` methods the reference's drivers touch (`eval/train/to/state_dict/
+load_state_dict/parameters`, models/diffusion/ddpm.py:50,118,209,288).  All
+arithmetic happens in libcrowdmod_hip.so; this class only owns the weights on
+the host and the native handle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+
+from . import native, spec
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+class UNet:
+    def __init__(self, input_channels=4, output_channels=4, num_res_blocks=2, base_channels=128,
+                 base_channels_multiples=(1, 2, 4, 8), apply_attention=(False, False, True, False, False),
+                 dropout_rate=0.1, time_multiple=4, condition="Past", *, device: int = 0, max_batch: int = 64,
+                 seed: Optional[int] = 42):
+        if condition != "Past":
+            raise NotImplementedError("only condition='Past' (the configuration every reference config uses)")
+        self.cfg = spec.UNetConfig(int(input_channels), int(output_channels), int(num_res_blocks), int(base_channels),
+                                   tuple(int(v) for v in base_channels_multiples),
+                                   tuple(bool(v) for v in apply_attention), float(dropout_rate), int(time_multiple),
+                                   condition)
+        self.input_channels = self.cfg.input_channels
+        self.condition = condition
+        self.device = int(device)
+        self.max_batch = int(max_batch)
+        self.training = False
+        self._shapes = spec.param_shapes(self.cfg)
+        # random init with torch-default ranges (the reference's nn.Module ctor does the same)
+        self._params: Dict[str, np.ndarray] = spec.init_params(self.cfg, seed if seed is not None else 0,
+                                                               perturb_norm=False)
+        self._handle = None
+        self._geom = None
+
+    # -- nn.Module surface ---------------------------------------------------------
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        self.training = bool(mode)
+        return self
+
+    def to(self, device=None):
+        if isinstance(device, int):
+            if device != self.device:
+                self._release()
+                self.device = device
+        return self
+
+    def parameters(self) -> Iterable[np.ndarray]:
+        return [v for k, v in self._params.items() if k != "time_embeddings.time_blocks.0.weight"]
+
+    def state_dict(self) -> Dict[str, np.ndarray]:
+        return {k: v.copy() for k, v in self._params.items()}
+
+    def load_state_dict(self, state: Dict[str, object], strict: bool = True):
+        got = {}
+        for k, v in state.items():
+            if _is_torch(v):
+                v = v.detach().cpu().numpy()
+            got[k] = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+        missing = [k for k in self._shapes if k not in got]
+        unexpected = [k for k in got if k not in self._shapes]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for UNet: missing keys {missing}, "
+                               f"unexpected keys {unexpected}")
+        for k, shp in self._shapes.items():
+            if k in got:
+                if tuple(got[k].shape) != tuple(shp):
+                    raise RuntimeError(f"size mismatch for {k}: got {tuple(got[k].shape)}, expected {tuple(shp)}")
+                self._params[k] = got[k]
+        self._release()
+        return self
+
+    # -- native handle -------------------------------------------------------------
+    def _release(self):
+        if self._handle is not None:
+            native.lib().cm_model_destroy(self._handle)
+            self._handle = None
+            self._geom = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def ensure(self, rows: int, cols: int, past_len: int, future_len: int, batch: int):
+        """Create (or re-create) the native model for this tensor geometry."""
+        geom = (rows, cols, past_len, future_len)
+        if self._handle is not None and self._geom == geom and batch <= self.max_batch:
+            return self._handle
+        self._release()
+        self.max_batch = max(self.max_batch, batch)
+        L = native.lib()
+        c = native.cm_unet_config()
+        c.in_channels, c.out_channels = self.cfg.input_channels, self.cfg.output_channels
+        c.num_res_blocks, c.base_channels = self.cfg.num_res_blocks, self.cfg.base_channels
+        c.n_levels = len(self.cfg.base_channels_multiples)
+        for i, v in enumerate(self.cfg.base_channels_multiples):
+            c.channel_mult[i] = v
+            c.apply_attention[i] = int(self.cfg.apply_attention[i])
+        c.time_multiple = self.cfg.time_multiple
+        c.rows, c.cols, c.past_len, c.future_len = rows, cols, past_len, future_len
+        c.max_batch, c.device = self.max_batch, self.device
+        h = C.c_void_p()
+        native.check(L.cm_model_create(C.byref(c), C.byref(h)))
+        try:
+            for name, arr in self._params.items():
+                arr = np.ascontiguousarray(arr, dtype=np.float32)
+                native.check(L.cm_model_set_param(h, name.encode(), arr.ctypes.data, arr.size))
+            native.check(L.cm_model_finalize(h))
+        except Exception:
+            L.cm_model_destroy(h)
+            raise
+        self._handle, self._geom = h, geom
+        return h
+
+    # -- forward -------------------------------------------------------------------
+    def __call__(self, future, t, past=None):
+        return self.forward(future, t, past)
+
+    def forward(self, future, t, past=None):
+        """UNet.forward (unet.py:124-167), eval mode.  numpy in -> numpy out (host
+        staging); torch CUDA tensors in -> torch CUDA tensor out (device pointers)."""
+        if past is None:
+            raise ValueError("condition='Past' needs the past frames")
+        if self.training:
+            raise NotImplementedError("training-mode forward (Dropout3d) is not part of this build yet")
+        L = native.lib()
+        B, Cc, H, W, F = (int(v) for v in future.shape)
+        P = int(past.shape[4])
+        if Cc != self.cfg.input_channels or tuple(past.shape[:4]) != (B, Cc, H, W):
+            raise ValueError(f"shape mismatch: future {tuple(future.shape)}, past {tuple(past.shape)}")
+        h = self.ensure(H, W, P, F, B)
+        if _is_torch(future):
+            import torch
+            if not future.is_cuda:
+                raise ValueError("torch inputs must live on the GPU; pass numpy arrays for host staging")
+            fut = future.contiguous().float()
+            pst = past.contiguous().float()
+            tt = t.to(device=future.device, dtype=torch.long).contiguous()
+            out = torch.empty_like(fut)
+            st = torch.cuda.current_stream(future.device).cuda_stream
+            native.check(L.cm_unet_forward(h, fut.data_ptr(), tt.data_ptr(), pst.data_ptr(), out.data_ptr(), B, st))
+            return out
+        fut = np.ascontiguousarray(future, dtype=np.float32)
+        pst = np.ascontiguousarray(past, dtype=np.float32)
+        tt = np.ascontiguousarray(np.broadcast_to(np.asarray(t, dtype=np.int64).reshape(-1), (B,)))
+        out = np.empty_like(fut)
+        native.check(L.cm_unet_forward_host(h, fut.ctypes.data, tt.ctypes.data, pst.ctypes.data, out.ctypes.data, B))
+        return out
+
+    def debug_activation(self, name: str) -> np.ndarray:
+        """Activation of the last forward by reference module name, layout [B,C,H,W,L]
+        (rows beyond the last batch are stale).  Test hook."""
+        L = native.lib()
+        if self._handle is None:
+            raise RuntimeError("no forward has run yet")
+        cap = 1 << 24
+        buf = np.empty(cap, dtype=np.float32)
+        shape = (C.c_int64 * 5)()
+        native.check(L.cm_debug_activation(self._handle, name.encode(), buf.ctypes.data, cap, shape))
+        shp = tuple(int(v) for v in shape)
+        return buf[: int(np.prod(shp))].reshape(shp).copy()
+
+    def cost(self, B: int):
+        f, b = C.c_double(), C.c_double()
+        native.check(native.lib().cm_model_cost(self._handle, B, C.byref(f), C.byref(b)))
+        return f.value, b.value

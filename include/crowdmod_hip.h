@@ -1,0 +1,177 @@
+/*
+ * crowdmod_hip.h -- C ABI of libcrowdmod_hip.so: the MI355X-native DDPM-UNet
+ * denoiser + sampler hot path of marcemq/crowdmod-ddpm-4D.
+ *
+ * The reference has no FFI of its own: the seam is three Python call
+ * signatures plus the checkpoint format.  Each entry
+ * point below names the reference interface it replaces.  All tensors that
+ * cross this ABI use the REFERENCE layout [B, C, H(rows), W(cols), L(frames)]
+ * fp32 contiguous, L innermost (utils/dataset.py:48-51); the library permutes
+ * to its internal channels-last layout on the device.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure;
+ *     cm_last_error() returns a thread-local description of the last failure;
+ *   - no exceptions cross the ABI; no torch / C++ types in signatures;
+ *   - handles are opaque, created and destroyed by the caller;
+ *   - the caller owns every buffer it passes in;
+ *   - "d_" pointers are device pointers on the handle's device, "h_" host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the handle's stream);
+ *   - one handle is not thread-safe; distinct handles on distinct devices are.
+ */
+#ifndef CROWDMOD_HIP_H
+#define CROWDMOD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CM_ABI_VERSION 1
+#define CM_MAX_LEVELS 8
+
+typedef struct cm_model cm_model;       /* UNet denoiser: weights + workspace   */
+typedef struct cm_schedule cm_schedule; /* ForwardSampler / DDPM schedule tables */
+
+/* Hyper-parameters of reference UNet.__init__ (models/backbones/unet.py:11-25)
+ * plus the tensor geometry the reference takes from cfg.MACROPROPS / cfg.DATASET
+ * (models/diffusion/ddpm.py:211). */
+typedef struct cm_unet_config {
+  int32_t in_channels;                    /* mprops_count: 3 or 4               */
+  int32_t out_channels;
+  int32_t num_res_blocks;                 /* NUM_RES_BLOCKS                     */
+  int32_t base_channels;                  /* BASE_CH (multiple of 8)            */
+  int32_t n_levels;                       /* len(BASE_CH_MULT)                  */
+  int32_t channel_mult[CM_MAX_LEVELS];    /* BASE_CH_MULT                       */
+  int32_t apply_attention[CM_MAX_LEVELS]; /* APPLY_ATTENTION (first n_levels)   */
+  int32_t time_multiple;                  /* TIME_EMB_MULT                      */
+  int32_t rows, cols;                     /* MACROPROPS.ROWS / COLS             */
+  int32_t past_len, future_len;           /* DATASET.PAST_LEN / FUTURE_LEN      */
+  int32_t max_batch;                      /* workspace is sized for this batch  */
+  int32_t device;                         /* HIP device ordinal                 */
+} cm_unet_config;
+
+/* ---- errors / info ------------------------------------------------------ */
+const char *cm_last_error(void);
+int cm_abi_version(void);
+int cm_device_count(int *count);
+
+/* ---- raw device memory (for hosts without a tensor library) ------------- */
+int cm_malloc(int device, void **d_ptr, size_t bytes);
+int cm_free(int device, void *d_ptr);
+int cm_memcpy_h2d(int device, void *d_dst, const void *h_src, size_t bytes);
+int cm_memcpy_d2h(int device, void *h_dst, const void *d_src, size_t bytes);
+int cm_memcpy_d2d(int device, void *d_dst, const void *d_src, size_t bytes);
+int cm_device_synchronize(int device);
+
+/* ---- denoiser: replaces UNet(...) / .load_state_dict / .state_dict ------ */
+/* unet.py:11-122 (ctor). */
+int cm_model_create(const cm_unet_config *cfg, cm_model **out);
+int cm_model_destroy(cm_model *m);
+/* state_dict() enumeration: names and shapes are the reference's (169 tensors
+ * for config/ATC.yml; conv weights [Co,Ci,kH,kW,kL]). */
+int cm_model_num_params(const cm_model *m, int32_t *count);
+int cm_model_param_info(const cm_model *m, int32_t index, const char **name, int64_t shape[5],
+                        int32_t *ndim);
+/* load_state_dict(): ddpm.py:161,288.  `numel` must match the tensor's size. */
+int cm_model_set_param(cm_model *m, const char *name, const float *h_data, int64_t numel);
+int cm_model_get_param(const cm_model *m, const char *name, float *h_data, int64_t numel);
+/* Packs weights into MFMA fragment order and precomputes the time-embedding
+ * tables; must be called after the last cm_model_set_param and before any
+ * forward.  Fails if a tensor was never set. */
+int cm_model_finalize(cm_model *m);
+
+/* UNet.forward(future, t, past) in eval mode -- unet.py:124-167.
+ *   d_future [B,C,H,W,F] f32, d_t [B] i64 in [0,1000), d_past [B,C,H,W,P] f32
+ *   d_out    [B,C,H,W,F] f32 (eps_hat).  B <= max_batch. */
+int cm_unet_forward(cm_model *m, const float *d_future, const int64_t *d_t, const float *d_past,
+                    float *d_out, int32_t B, void *stream);
+/* Same with host buffers (staged through the workspace; synchronous). */
+int cm_unet_forward_host(cm_model *m, const float *h_future, const int64_t *h_t, const float *h_past,
+                         float *h_out, int32_t B);
+/* Test hook: copy an internal activation (by reference module name, e.g.
+ * "encoder_blocks.0") of the last forward to the host in reference layout
+ * [B,C,H,W,L].  `shape` receives {B,C,H,W,L}. */
+int cm_debug_activation(cm_model *m, const char *name, float *h_out, int64_t capacity,
+                        int64_t shape[5]);
+
+/* ---- schedule: replaces ForwardSampler.__init__ (forward.py:10-27) ------ */
+int cm_schedule_create(int32_t timesteps, float scale, float beta_start, float beta_end,
+                       int32_t device, cm_schedule **out);
+int cm_schedule_destroy(cm_schedule *s);
+enum {
+  CM_TAB_BETA = 0,
+  CM_TAB_ALPHA = 1,
+  CM_TAB_ALPHA_BAR = 2,
+  CM_TAB_SQRT_ALPHA_BAR = 3,
+  CM_TAB_ONE_BY_SQRT_ALPHA = 4,
+  CM_TAB_SQRT_ONE_MINUS_ALPHA_BAR = 5
+};
+/* The six [T] buffers the reference exposes as attributes (ddpm.py:246-248). */
+int cm_schedule_table(const cm_schedule *s, int32_t which, float *h_out, int32_t capacity);
+
+/* ---- sampler steps ------------------------------------------------------- */
+/* ForwardSampler.forward (forward.py:29-36) with the noise supplied by the
+ * caller: d_xt = sqrt_alpha_bar[t_b] * x0 + sqrt_one_minus_alpha_bar[t_b] * eps.
+ * per_sample = C*H*W*F. */
+int cm_q_sample(const cm_schedule *s, const float *d_x0, const int64_t *d_t, const float *d_eps,
+                float *d_xt, int32_t B, int64_t per_sample, void *stream);
+/* DDPM.step (ddpm.py:25-38): d_x is updated in place.  d_noise == NULL draws
+ * z from the device Philox stream (seed, sample_id_base + b, step t); it is
+ * ignored (z = 0) when t == 0, as in the reference. */
+int cm_ddpm_step(const cm_schedule *s, const float *d_eps, float *d_x, int32_t t, const float *d_noise,
+                 uint64_t seed, int64_t sample_id_base, int32_t B, int64_t per_sample, void *stream);
+
+/* ---- whole reverse loop --------------------------------------------------- */
+enum { CM_SAMPLER_DDPM = 0, CM_SAMPLER_DDIM = 1 };
+enum { CM_GUIDANCE_NONE = 0, CM_GUIDANCE_SPARSITY = 1 };
+
+typedef struct cm_sample_opts {
+  int32_t sampler;        /* cfg.MODEL.DDPM.SAMPLER                              */
+  int32_t guidance;       /* cfg.MODEL.DDPM.GUIDANCE ("None" | "Sparsity")       */
+  float lambda_guidance;  /* cfg.MODEL.DDPM.LAMBDA_GUIDANCE                      */
+  float ddim_sigma;       /* cfg.MODEL.DDPM.SIGMA                                */
+  int32_t ddim_divider;   /* cfg.MODEL.DDPM.DDIM_DIVIDER: taus = arange(0,T-1,d) */
+  int32_t first_steps;    /* >0: run only the first n visited steps (benchmarks) */
+  uint64_t seed;          /* device RNG seed (used when x_T / noise are NULL)    */
+  int64_t sample_id_base; /* global index of sample 0 (batch sharding)           */
+  int32_t use_graph;      /* replay the per-step launch sequence as a hipGraph   */
+  int32_t reserved;
+} cm_sample_opts;
+
+/* DDPM_model._generate_ddpm / _generate_ddim (ddpm.py:206-282): all T (or
+ * len(taus)) steps run on the device behind this one call.
+ *   d_past   [B,C,H,W,P]
+ *   d_xT     [B,C,H,W,F] or NULL (draw from the device RNG)
+ *   d_noise  [nsteps,B,C,H,W,F] in visiting order, or NULL (device RNG).
+ *            DDPM: step k is t = T-1-k, rows for t = 0 are not read
+ *            (nsteps = T-1 suffices); DDIM: step k is reversed(taus)[k].
+ *   d_out    [B,C,H,W,F] final sample x_0
+ *   d_history NULL, or [nsteps+1,B,C,H,W,F]: x_T followed by x after every step
+ *            (the `history=True` list of the reference). */
+int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const float *d_xT,
+                   const float *d_noise, const cm_sample_opts *opts, float *d_out, float *d_history,
+                   int32_t B, void *stream);
+/* Host-buffer variant (synchronous). */
+int cm_sample_loop_host(cm_model *m, const cm_schedule *s, const float *h_past, const float *h_xT,
+                        const float *h_noise, const cm_sample_opts *opts, float *h_out,
+                        float *h_history, int32_t B);
+/* Number of UNet evaluations cm_sample_loop performs for these options. */
+int cm_sample_num_steps(const cm_schedule *s, const cm_sample_opts *opts, int32_t *nsteps);
+
+/* ---- instrumentation ------------------------------------------------------ */
+/* Per-kernel-class device time of the LAST forward/loop, measured with HIP
+ * events on the launch stream when enabled (adds synchronisation; off by
+ * default).  classes: 0 conv3x3x3, 1 conv1x1x1/GEMM, 2 stats+GN, 3 attention,
+ * 4 elementwise (assemble/step).  `ms` and `launches` hold 8 entries. */
+int cm_profile_enable(cm_model *m, int32_t on);
+int cm_profile_read(cm_model *m, float ms[8], int64_t launches[8]);
+/* Algorithmic FLOPs and bytes of one forward at batch B. */
+int cm_model_cost(const cm_model *m, int32_t B, double *flops, double *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CROWDMOD_HIP_H */

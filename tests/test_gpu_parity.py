@@ -1,0 +1,182 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the golden vectors captured
+from the reference and vs the oracle.  Run on the MI355X box with `-m gpu`."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from crowdmod_ddpm_4d_amd import prng, spec
+from helpers import FULL_GRIDS, NARROW, SEED_W, full_cfg, load, loop_noise, narrow_cfg, synth_inputs
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north_star: <= 1e-4 max-abs vs reference (fp32)
+
+
+def _unet(cfg, params, max_batch=2):
+    from crowdmod_ddpm_4d_amd.unet import UNet
+    net = UNet(cfg.input_channels, cfg.output_channels, cfg.num_res_blocks, cfg.base_channels,
+               cfg.base_channels_multiples, cfg.apply_attention, cfg.dropout_rate, cfg.time_multiple, "Past",
+               max_batch=max_batch)
+    net.load_state_dict(params)
+    return net
+
+
+@pytest.mark.parametrize("C_", [3, 4])
+def test_narrow_forward_every_block(C_):
+    g = load(f"ops_c{C_}.npz")
+    cfg = narrow_cfg(C_)
+    P = spec.init_params(cfg, SEED_W)
+    geo = NARROW
+    past, fut = synth_inputs(geo["B"], C_, geo["H"], geo["W"], geo["P"], geo["F"], f"narrow{C_}")
+    net = _unet(cfg, P)
+    y = net(fut, g["t"], past)
+    plan = spec.make_plan(cfg)
+    names = ["first"] + [b.prefix for b in plan.encoder + plan.bottleneck + plan.decoder]
+    worst = {}
+    for name in names:
+        act = net.debug_activation(name)[: geo["B"]]
+        ref = g[name + "/out"]
+        assert act.shape == ref.shape, (name, act.shape, ref.shape)
+        worst[name] = float(np.abs(act - ref).max())
+    bad = {k: v for k, v in worst.items() if v > TOL}
+    assert not bad, f"blocks beyond tolerance: {bad} (all: {worst})"
+    assert np.abs(y - g["out"]).max() <= TOL
+
+
+@pytest.mark.parametrize("key", ["atc_c3", "atc_c4", "cr120_c3", "atc2x_c3"])
+def test_full_forward_vs_reference(key):
+    g = load("fwd.npz")
+    gname, c = key.split("_c")
+    C_ = int(c)
+    H, W = FULL_GRIDS[gname]
+    cfg = full_cfg(C_)
+    P = spec.init_params(cfg, SEED_W)
+    past, fut = synth_inputs(2, C_, H, W, 5, 3, f"full/{gname}/c{C_}")
+    net = _unet(cfg, P)
+    y = net(fut, g[f"{key}/t"], past)
+    err = float(np.abs(y - g[f"{key}/out"]).max())
+    assert err <= TOL, err
+
+
+def test_forward_batch_independence_and_odd_batch():
+    """Chains are independent: sample i of a batch of 5 equals sample i run alone
+    (the property the multi-GPU batch shard relies on)."""
+    cfg = narrow_cfg(3)
+    P = spec.init_params(cfg, SEED_W)
+    past, fut = synth_inputs(5, 3, 4, 8, 5, 3, "odd")
+    t = np.array([0, 1, 500, 998, 999], dtype=np.int64)
+    net = _unet(cfg, P, max_batch=5)
+    full = net(fut, t, past)
+    for i in (0, 4):
+        one = net(fut[i:i + 1], t[i:i + 1], past[i:i + 1])
+        assert np.array_equal(one[0], full[i]), i
+
+
+def _loop_inputs(tag):
+    C_, H, W, P_, F, B = 3, 12, 36, 5, 3, 2
+    per = C_ * H * W * F
+    past = prng.normal(7, f"past/loop/{tag}", B * C_ * H * W * P_).reshape(B, C_, H, W, P_)
+    x_T = prng.normal_per_sample(7, f"xT/{tag}", np.arange(B), per).reshape(B, C_, H, W, F)
+    return past, x_T, per, (B, C_, H, W, F)
+
+
+def _model(T, guidance="None", lam=0.0, sigma=0.001, divider=2, sampler="DDPM"):
+    from crowdmod_ddpm_4d_amd.config import AttrDict
+    from crowdmod_ddpm_4d_amd.ddpm_model import DDPM_model
+    cfg = AttrDict({
+        "MACROPROPS": {"ROWS": 12, "COLS": 36}, "DATASET": {"PAST_LEN": 5, "FUTURE_LEN": 3, "BATCH_SIZE": 2},
+        "MODEL": {"NSAMPLES": 2, "NSAMPLES4PLOTS": 2, "DDPM": {
+            "SAMPLER": sampler, "TIMESTEPS": T, "SCALE": 0.5, "SIGMA": sigma, "DDIM_DIVIDER": divider,
+            "GUIDANCE": guidance, "LAMBDA_GUIDANCE": lam,
+            "UNET": {"CONDITION": "Past", "NUM_RES_BLOCKS": 1, "BASE_CH": 32, "BASE_CH_MULT": [1, 2, 4],
+                     "APPLY_ATTENTION": [False, False, True, False], "DROPOUT_RATE": 0.1, "TIME_EMB_MULT": 4}}}})
+    m = DDPM_model(cfg, "DDPM-UNet", 3)
+    m.denoiser.load_state_dict(spec.init_params(full_cfg(3), SEED_W))
+    return m
+
+
+@pytest.mark.parametrize("tag,T,guid", [("ddpm50", 50, "None"), ("ddpm20_sparsity", 20, "Sparsity")])
+def test_loop_ddpm_vs_reference(tag, T, guid):
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    g = load("loop.npz")
+    past, x_T, per, shape = _loop_inputs(tag)
+    noise = np.stack([loop_noise(tag, 2, per, t).reshape(shape) for t in range(T - 1, 0, -1)])
+    m = _model(T, guid, 0.004)
+    x, lst = m._generate_ddpm(past, DDPM(timesteps=T, scale=0.5), 2, x_T=x_T, noise=noise)
+    err = float(np.abs(x - g[tag + "/x0"]).max())
+    assert err <= TOL, err
+    assert lst[0] is x_T and lst[-1] is x
+
+
+@pytest.mark.parametrize("guid", ["None", "Sparsity"])
+def test_loop_ddim_vs_reference(guid):
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    g = load("loop.npz")
+    tag = "ddim1000_div100" + ("_sparsity" if guid == "Sparsity" else "")
+    past, x_T, per, shape = _loop_inputs(tag)
+    taus = np.arange(0, 999, 100)
+    noise = np.stack([loop_noise(tag, 2, per, int(t)).reshape(shape) for t in reversed(taus)])
+    m = _model(1000, guid, 0.004, sigma=0.001, divider=100, sampler="DDIM")
+    x, _ = m._generate_ddim(past, taus, DDPM(timesteps=1000, scale=0.5), 2, x_T=x_T, noise=noise)
+    ref = g[tag + "/x0"]
+    err = float(np.abs(x - ref).max() / max(1.0, np.abs(ref).max()))
+    assert err <= TOL, err
+
+
+def test_loop_ddpm1000_history_vs_reference():
+    """Full-length loop (BASELINE config 2 length, B=2) with history; bar relative to
+    |x|max because the reference itself moves by 5e-5 with the thread count here."""
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    g = load("loop.npz")
+    tag, T = "ddpm1000", 1000
+    past, x_T, per, shape = _loop_inputs(tag)
+    noise = np.stack([loop_noise(tag, 2, per, t).reshape(shape) for t in range(T - 1, 0, -1)])
+    m = _model(T)
+    x, hist = m._generate_ddpm(past, DDPM(timesteps=T, scale=0.5), 2, history=True, x_T=x_T, noise=noise)
+    assert len(hist) == T + 1 and np.array_equal(hist[0], x_T) and np.array_equal(hist[-1], x)
+    for t in (999, 900, 500, 0):
+        ref = g[f"{tag}/x_after_t{t}"]
+        got = hist[1 + (T - 1 - t)]
+        rel = float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
+        assert rel <= 2e-5, (t, rel)
+
+
+def test_schedule_q_sample_and_step_vs_golden():
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    from oracle import unet_numpy as on
+    g = load("schedule.npz")
+    s = DDPM(timesteps=1000, scale=0.5)
+    for k in ("beta", "alpha", "alpha_bar"):
+        assert np.array_equal(getattr(s, k), g[f"T1000_s0.5/{k}"]), k
+    for k in ("sqrt_alpha_bar", "one_by_sqrt_alpha", "sqrt_one_minus_alpha_bar"):
+        np.testing.assert_allclose(getattr(s, k), g[f"T1000_s0.5/{k}"], rtol=1.2e-7)
+    x0 = prng.normal(7, "qs/x0", 4 * 3 * 4 * 8 * 3).reshape(4, 3, 4, 8, 3)
+    eps = prng.normal(7, "qs/eps", 4 * 3 * 4 * 8 * 3).reshape(4, 3, 4, 8, 3)
+    xt, e = s(x0, g["qsample/t"], noise=eps)
+    np.testing.assert_allclose(xt, g["qsample/xt"], rtol=0, atol=1e-6)
+    sched = on.schedule(1000, 0.5)
+    for t in (999, 500, 1, 0):
+        want, sig, a = on.ddpm_step(sched, eps, x0, t, x0[::-1].copy() if t > 0 else np.zeros_like(x0))
+        got, sig2, a2 = s.step(eps, x0, t, noise=x0[::-1].copy())
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+        assert abs(sig - sig2) < 1e-7 and abs(a - a2) < 1e-7
+
+
+def test_device_rng_is_shard_independent_and_normal():
+    """x_T / z_t drawn on the device depend only on (seed, global sample id, step)."""
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    m = _model(4)
+    past, _, per, shape = _loop_inputs("rng")
+    past4 = np.concatenate([past, past[::-1]])
+    s = DDPM(timesteps=4, scale=0.5)
+    m.seed = 123
+    m._sample_calls = 0
+    full, hist = m._generate_ddpm(past4, s, 4, history=True)
+    m._sample_calls = 0
+    lo, _ = m._generate_ddpm(past4[:2], s, 2, sample_id_base=0)
+    m._sample_calls = 0
+    hi, _ = m._generate_ddpm(past4[2:], s, 2, sample_id_base=2)
+    assert np.array_equal(full[:2], lo) and np.array_equal(full[2:], hi)
+    xT = hist[0]
+    assert abs(float(xT.mean())) < 0.05 and abs(float(xT.std()) - 1.0) < 0.05
