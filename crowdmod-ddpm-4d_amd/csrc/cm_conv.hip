@@ -21,14 +21,17 @@
 //     wave applies bias + time-embedding + residual and stores channels-last.
 #include "cm_kernels.h"
 
+#include <cstdlib>
+
 namespace cm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division sequence
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-template <int MB, int NB>
+template <int MB, int NB, bool FAST>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TM = 32 * MB;
@@ -47,6 +50,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int tz = tile % a.ntz;
   const int ts = tile / a.ntz;
   const int nt = blockIdx.y;
+  // De-phase the workgroups that share a CU.  They are identical programs started
+  // together, so left alone they stage, compute and store in lock-step and the matrix
+  // cores idle during everybody's load/store phases.  Delaying the second resident
+  // set once is enough: every later workgroup starts when an earlier one retires.
+  // (Placement is not architecturally defined -- a wrong guess only costs the delay.)
+  if (a.stagger > 0) {
+    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+    const unsigned slot = lin >> 8;  // 256 CUs: blocks b and b+256 are expected to share a CU
+    if (slot >= 1 && slot < 4 && (slot & 1)) {
+      for (int i = 0; i < a.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
+    }
+  }
   const int b0 = ts * a.bs, z0 = tz * a.bz, y0 = ty * a.by, x0 = tx * a.bx;
 
   const int pad = (a.ntaps == 27) ? 1 : 0;
@@ -60,54 +75,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int nbox = a.bs * a.bz * a.by * a.bx;
 
   int *outoff = reinterpret_cast<int *>(lds);  // [TM] output voxel index or -1
-  int *srcoff = outoff + TM;                   // [HVp] source voxel index or -1
-  float *A = lds + TM + HVp;                   // [HV][S] staged halo tile / reduction scratch
+  int *outb = outoff + TM;                     // [TM] sample index of the row
+  float *A = lds + 2 * TM;                     // [HV][S] staged halo tile / reduction scratch
+  (void)HVp;
 
-  // ---- index tables -----------------------------------------------------
+  // ---- output row table (coordinates come packed from the host: no divisions) ----
   for (int m = tid; m < TM; m += 256) {
-    int off = -1;
-    if (m < nbox) {
-      const int x = m % a.bx;
-      int q = m / a.bx;
-      const int y = q % a.by; q /= a.by;
-      const int z = q % a.bz;
-      const int s = q / a.bz;
+    const int pk = a.mtab[m];
+    int off = -1, bb = 0;
+    if (pk >= 0) {
+      const int x = pk & 511, y = (pk >> 9) & 511, z = (pk >> 18) & 255, s = pk >> 26;
       const int b = b0 + s, oz = z0 + z, oy = y0 + y, ox = x0 + x;
+      bb = b < a.B ? b : 0;
       if (b < a.B && oz < a.Zo && oy < a.Yo && ox < a.Xo) off = ((b * a.Zo + oz) * a.Yo + oy) * a.Xo + ox;
     }
     outoff[m] = off;
+    outb[m] = bb;
   }
-  {
-    const int Zc = a.Zs << a.ups, Yc = a.Ys << a.ups, Xc = a.Xs << a.ups;
-    for (int hv = tid; hv < HVp; hv += 256) {
-      int off = -1;
-      if (hv < HV) {
-        const int hx = hv % HX;
-        int q = hv / HX;
-        const int hy = q % HY; q /= HY;
-        const int hz = q % HZ;
-        const int s = q / HZ;
-        const int b = b0 + s;
-        const int cz = z0 * a.stride - pad + hz, cy = y0 * a.stride - pad + hy, cx = x0 * a.stride - pad + hx;
-        if (b < a.B && cz >= 0 && cz < Zc && cy >= 0 && cy < Yc && cx >= 0 && cx < Xc)
-          off = ((b * a.Zs + (cz >> a.ups)) * a.Ys + (cy >> a.ups)) * a.Xs + (cx >> a.ups);
-      }
-      srcoff[hv] = off;
-    }
-  }
+  const int Zc = a.Zs << a.ups, Yc = a.Ys << a.ups, Xc = a.Xs << a.ups;
+  const int cz0 = z0 * a.stride - pad, cy0 = y0 * a.stride - pad, cx0 = x0 * a.stride - pad;
 
   // ---- per-lane LDS row base of each of this wave's MB row blocks -----------
   int abase[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    const int m = mb * 32 + r;
+    const int pk = a.mtab[mb * 32 + r];
     int hv = 0;
-    if (m < nbox) {
-      const int x = m % a.bx;
-      int q = m / a.bx;
-      const int y = q % a.by; q /= a.by;
-      const int z = q % a.bz;
-      const int s = q / a.bz;
+    if (pk >= 0) {
+      const int x = pk & 511, y = (pk >> 9) & 511, z = (pk >> 18) & 255, s = pk >> 26;
       hv = ((s * HZ + z * a.stride) * HY + y * a.stride) * HX + x * a.stride;
     }
     abase[mb] = hv * S + 4 * h;
@@ -129,6 +124,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
   const int q4 = tid % K4, v0 = tid / K4, vstep = 256 / K4;
 
+  constexpr int PD = 3;  // weight prefetch depth of the fast path (steps)
+  constexpr bool fast = FAST;  // host guarantees CK == 32 && ntaps == 27
+  f32x4 bq[PD][NB];
+  if constexpr (fast) {
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      const f32x4 *wp = wtile + (size_t)(wave + 4 * d) * NB * 64;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bq[d][nb] = wp[nb * 64];
+    }
+  }
+
   for (int ch = 0; ch < nchunks; ++ch) {
     const float *src;
     int Cs, c0, cg0;
@@ -136,50 +143,123 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     else { src = a.src1; Cs = a.C1; c0 = (ch - a.nch0) * a.CK; cg0 = a.C0 + c0; }
     __syncthreads();  // tables ready (first pass) / previous chunk fully consumed
     // ---- stage the halo tile of this channel chunk ---------------------------
-    for (int hv = v0; hv < HV; hv += vstep) {
-      const int off = srcoff[hv];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (off >= 0) {
-        v = *reinterpret_cast<const f32x4 *>(src + (size_t)off * Cs + c0 + 4 * q4);
+    // (loads are issued in batches of SU so that their latencies overlap)
+    constexpr int SU = 4;
+    const float *srcq = src + c0 + 4 * q4;
+    // Branch-free: loads inside divergent branches make hipcc fall back to vmcnt(0) waits.
+    // Out-of-range halo voxels read voxel 0 (a cached line) and are zeroed before the
+    // LDS write; the hvtab entries beyond HV are clamped to the last valid one.
+    for (int hv0 = v0; hv0 < HV && !(a.dbg & 1); hv0 += vstep * SU) {
+      int pk[SU];
+      f32x4 v[SU], sc[SU], sh[SU];
+      bool ok[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int hv = hv0 + u * vstep;
+        pk[u] = a.hvtab[hv < HV ? hv : HV - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int hv = hv0 + u * vstep;
+        const int cx = cx0 + (pk[u] & 511), cy = cy0 + ((pk[u] >> 9) & 511), cz = cz0 + ((pk[u] >> 18) & 255);
+        const int b = b0 + (pk[u] >> 26);
+        ok[u] = hv < HV && b < a.B && cz >= 0 && cz < Zc && cy >= 0 && cy < Yc && cx >= 0 && cx < Xc;
+        const int off = ok[u] ? ((b * a.Zs + (cz >> a.ups)) * a.Ys + (cy >> a.ups)) * a.Xs + (cx >> a.ups) : 0;
+        const int bb = b < a.B ? b : 0;
+        v[u] = *reinterpret_cast<const f32x4 *>(srcq + (size_t)off * Cs);
         if (a.gn) {
-          const int b = b0 + (a.bs == 1 ? 0 : hv / HV1);
-          const float *g = a.gn + (size_t)b * 2 * Ctot + cg0 + 4 * q4;
-          const f32x4 sc = *reinterpret_cast<const f32x4 *>(g);
-          const f32x4 sh = *reinterpret_cast<const f32x4 *>(g + Ctot);
-          v = v * sc + sh;
-          if (a.silu) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+          const float *g = a.gn + (size_t)bb * 2 * Ctot + cg0 + 4 * q4;
+          sc[u] = *reinterpret_cast<const f32x4 *>(g);
+          sh[u] = *reinterpret_cast<const f32x4 *>(g + Ctot);
         }
       }
-      *reinterpret_cast<f32x4 *>(&A[hv * S + 4 * q4]) = v;
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int hv = hv0 + u * vstep;
+        f32x4 w = v[u];
+        if (a.gn) {
+          w = w * sc[u] + sh[u];
+          if (a.silu) { w[0] = silu_f(w[0]); w[1] = silu_f(w[1]); w[2] = silu_f(w[2]); w[3] = silu_f(w[3]); }
+        }
+        if (!ok[u]) w = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hv < HV) *reinterpret_cast<f32x4 *>(&A[hv * S + 4 * q4]) = w;
+      }
     }
     __syncthreads();
     // ---- this wave's share of the (tap, 8-channel) steps ---------------------
-    const f32x4 *wch = wtile + (size_t)ch * nsteps * NB * 64;
-    for (int s = wave; s < nsteps; s += 4) {
-      const int t = s / K8, j = s - t * K8;
-      int tapoff = 0;
-      if (a.ntaps == 27) {
-        const int dz = t / 9, rem = t - dz * 9, dy = rem / 3, dx = rem - dy * 3;
-        tapoff = (dz * HY + dy) * HX + dx;
+    if (a.dbg & 2) continue;
+    if constexpr (fast) {
+      // 27 taps x 4 k8-steps = 108 steps per chunk, 27 per wave: wave w owns channels
+      // [8w, 8w+8) of the chunk for every tap.  Weight fragments run PD steps ahead of
+      // the MFMAs in a register ring (static indices: 27 = 9 x PD) and the stream
+      // continues across chunk boundaries, so neither the L2 latency nor the staging
+      // barrier exposes a weight load.
+#pragma unroll 1
+      for (int i0 = 0; i0 < 27; i0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+          const int t = i0 + d;  // tap index
+          const int dz = t / 9, rem = t - dz * 9, dy = rem / 3, dx = rem - dy * 3;
+          const int aoff = ((dz * HY + dy) * HX + dx) * S + wave * 8;
+          f32x4 af[MB];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) af[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + aoff]);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mb][jj], bq[d][nb][jj], acc[mb][nb], 0, 0, 0);
+          // refill this ring slot with the fragments PD steps ahead (possibly next chunk)
+          int tn = t + PD, chn = ch;
+          if (tn >= 27) { tn -= 27; chn += 1; }
+          if (chn < nchunks) {
+            const f32x4 *wp = wtile + ((size_t)chn * 108 + (wave + 4 * tn)) * NB * 64;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bq[d][nb] = wp[nb * 64];
+          }
+        }
       }
-      const int aoff = tapoff * S + j * 8;
-      f32x4 bf[NB], af[MB];
+    } else {
+      const f32x4 *wch = wtile + (size_t)ch * nsteps * NB * 64;
+      f32x4 bf[NB], bfn[NB];
+      if (wave < nsteps) {
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) bf[nb] = wch[(size_t)(s * NB + nb) * 64];
+        for (int nb = 0; nb < NB; ++nb) bf[nb] = wch[(size_t)(wave * NB + nb) * 64];
+      }
+      for (int s = wave; s < nsteps; s += 4) {
+        const int t = s / K8, j = s - t * K8;
+        int tapoff = 0;
+        if (a.ntaps == 27) {
+          const int dz = t / 9, rem = t - dz * 9, dy = rem / 3, dx = rem - dy * 3;
+          tapoff = (dz * HY + dy) * HX + dx;
+        }
+        const int aoff = tapoff * S + j * 8;
+        const int sn = (s + 4 < nsteps) ? s + 4 : s;
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) af[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + aoff]);
+        for (int nb = 0; nb < NB; ++nb) bfn[nb] = wch[(size_t)(sn * NB + nb) * 64];
+        f32x4 af[MB];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
+        for (int mb = 0; mb < MB; ++mb) af[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + aoff]);
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mb][jj], bf[nb][jj], acc[mb][nb], 0, 0, 0);
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mb][jj], bf[nb][jj], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bf[nb] = bfn[nb];
+      }
     }
   }
 
   // ---- cross-wave reduction (rounds of RB blocks) + epilogue -------------------
-  const int vox_out = a.Zo * a.Yo * a.Xo;
+  if (a.dbg & 4) {
+    if (acc[0][0][0] == 123.456f) a.out[0] = 1.f;  // keep the accumulators live
+    return;
+  }
 #pragma unroll
   for (int g0 = 0; g0 < NBLK; g0 += RB) {
     __syncthreads();  // A tile (or previous round's scratch) no longer read
@@ -203,30 +283,53 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       const int blk = g0 + i;
       if (blk < NBLK && wave == (blk & 3)) {
         const int mb = blk / NB, nb = blk % NB;
-        f32x16 v = acc[mb][nb];
+        // sum the four partials in wave order 0..3 whatever the owner: the result
+        // must not depend on the tile geometry (batch-shard bit-exactness)
+        const int owner = blk & 3;
+        f32x16 v;
 #pragma unroll
-        for (int slot = 0; slot < 3; ++slot) {
-          const float *sp = A + ((i * 3 + slot) * 16) * 64 + lane;
+        for (int reg = 0; reg < 16; ++reg) v[reg] = 0.f;
 #pragma unroll
-          for (int reg = 0; reg < 16; ++reg) v[reg] += sp[reg * 64];
+        for (int w = 0; w < 4; ++w) {
+          if (w == owner) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) v[reg] += acc[mb][nb][reg];
+          } else {
+            const int slot = w - (w > owner ? 1 : 0);
+            const float *sp = A + ((i * 3 + slot) * 16) * 64 + lane;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) v[reg] += sp[reg * 64];
+          }
         }
         const int n = nt * TN + nb * 32 + r;
-        if (n < a.Co) {
-          const float bias = a.bias[n];
+        {
+          // branch-free gathers, then the stores (see the note on wait counts above)
+          const bool nok = n < a.Co;
+          const int nc = nok ? n : 0;
+          const float bias = a.bias[nc];
+          int offs[16];
+          float rs[16];
 #pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const int m = mb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            const int off = outoff[m];
-            if (off >= 0) {
-              float o = v[reg] + bias;
-              if (a.temb) {
-                const int b = off / vox_out;
-                o += a.temb[(size_t)a.tidx[b] * a.temb_stride + n];
-              }
-              if (a.resid) o += a.resid[(size_t)off * a.res_cs + n];
-              a.out[(size_t)off * a.out_cs + n] = o;
+          for (int reg = 0; reg < 16; ++reg) offs[reg] = outoff[mb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h];
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) rs[reg] = v[reg] + bias;
+          if (a.temb) {  // wave-uniform
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const long long t = a.tidx[outb[mb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h]];
+              rs[reg] += a.temb[(size_t)t * a.temb_stride + nc];
             }
           }
+          if (a.resid) {  // wave-uniform
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int oc = offs[reg] >= 0 ? offs[reg] : 0;
+              rs[reg] += a.resid[(size_t)oc * a.res_cs + nc];
+            }
+          }
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg)
+            if (nok && offs[reg] >= 0) a.out[(size_t)offs[reg] * a.out_cs + n] = rs[reg];
         }
       }
     }
@@ -245,8 +348,39 @@ size_t conv_lds_bytes(const ConvArgs &a, int MB, int NB) {
   const int rb = nblk < 4 ? nblk : 4;
   size_t tile = (size_t)HV * S;
   size_t red = (size_t)rb * 3 * 16 * 64;
-  size_t words = (size_t)32 * MB + HVp + (tile > red ? tile : red);
+  (void)HVp;
+  size_t words = (size_t)64 * MB + (tile > red ? tile : red);
   return words * 4;
+}
+
+int conv_halo_voxels(const ConvArgs &a) {
+  const int pad = (a.ntaps == 27) ? 1 : 0;
+  const int HZ = (a.bz - 1) * a.stride + 1 + 2 * pad;
+  const int HY = (a.by - 1) * a.stride + 1 + 2 * pad;
+  const int HX = (a.bx - 1) * a.stride + 1 + 2 * pad;
+  return a.bs * HZ * HY * HX;
+}
+
+void conv_build_tables(const ConvArgs &a, int MB, int *hvtab, int *mtab) {
+  const int pad = (a.ntaps == 27) ? 1 : 0;
+  const int HZ = (a.bz - 1) * a.stride + 1 + 2 * pad;
+  const int HY = (a.by - 1) * a.stride + 1 + 2 * pad;
+  const int HX = (a.bx - 1) * a.stride + 1 + 2 * pad;
+  int i = 0;
+  for (int s = 0; s < a.bs; ++s)
+    for (int hz = 0; hz < HZ; ++hz)
+      for (int hy = 0; hy < HY; ++hy)
+        for (int hx = 0; hx < HX; ++hx) hvtab[i++] = (s << 26) | (hz << 18) | (hy << 9) | hx;
+  const int nbox = a.bs * a.bz * a.by * a.bx;
+  for (int m = 0; m < 32 * MB; ++m) {
+    if (m >= nbox) { mtab[m] = -1; continue; }
+    const int x = m % a.bx;
+    int q = m / a.bx;
+    const int y = q % a.by; q /= a.by;
+    const int z = q % a.bz;
+    const int s = q / a.bz;
+    mtab[m] = (s << 26) | (z << 18) | (y << 9) | x;
+  }
 }
 
 #define CM_CONV_VARIANTS(X) \
@@ -261,23 +395,42 @@ bool conv_variant_exists(int MB, int NB) {
   return false;
 }
 
-hipError_t launch_conv(const ConvArgs &a, int MB, int NB, hipStream_t st) {
+hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
+  static const int dbg = getenv("CM_CONV_DBG") ? atoi(getenv("CM_CONV_DBG")) : 0;  // ablation switches (perf studies only)
+  static const int stg = getenv("CM_CONV_STAGGER") ? atoi(getenv("CM_CONV_STAGGER")) : -1;
+  ConvArgs a = a_in;
+  a.dbg = dbg;
+  if (stg >= 0) a.stagger = stg;
   const size_t lds = conv_lds_bytes(a, MB, NB);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int TN = 32 * NB;
   dim3 grid((unsigned)(a.nts * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + TN - 1) / TN));
+  const bool fast = (a.CK == 32 && a.ntaps == 27);
 #define X(m, n)                                                                              \
+  if (MB == m && NB == n && fast) {                                                          \
+    static bool attr_set[64] = {false};                                                      \
+    int dev = 0;                                                                             \
+    (void)hipGetDevice(&dev);                                                                \
+    if (!attr_set[dev & 63]) {                                                               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<m, n, true>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (e != hipSuccess) return e;                                                         \
+      attr_set[dev & 63] = true;                                                             \
+    }                                                                                        \
+    hipLaunchKernelGGL((conv_mfma_kernel<m, n, true>), grid, dim3(256), lds, st, a);           \
+    return hipGetLastError();                                                                \
+  }                                                                                          \
   if (MB == m && NB == n) {                                                                  \
     static bool attr_set[64] = {false};                                                      \
     int dev = 0;                                                                             \
     (void)hipGetDevice(&dev);                                                                \
     if (!attr_set[dev & 63]) {                                                               \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<m, n>), \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<m, n, false>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       if (e != hipSuccess) return e;                                                         \
       attr_set[dev & 63] = true;                                                             \
     }                                                                                        \
-    hipLaunchKernelGGL((conv_mfma_kernel<m, n>), grid, dim3(256), lds, st, a);                 \
+    hipLaunchKernelGGL((conv_mfma_kernel<m, n, false>), grid, dim3(256), lds, st, a);          \
     return hipGetLastError();                                                                \
   }
   CM_CONV_VARIANTS(X)

@@ -40,13 +40,27 @@ struct ConvArgs {
   int nts, ntz, nty, ntx;  // number of boxes along each of those
   int CK;              // channel chunk staged per pass: 8, 16 or 32
   int nch0, nch1;      // chunks in src0 / src1
+  const int *hvtab;    // [HV] packed halo-box coordinates  s<<26 | hz<<18 | hy<<9 | hx  (host-built)
+  const int *mtab;     // [32*MB] packed output-box coordinates s<<26 | z<<18 | y<<9 | x, or -1 (padding row)
   float *stat_part;    // optional fused per-channel statistics partials (unused in v1)
+  int dbg;             // ablation switches for performance studies (0 in production)
+  int stagger;         // start delay (in 64-cycle units) applied to every other first-wave workgroup
 };
 
 size_t conv_lds_bytes(const ConvArgs &a, int MB, int NB);
+// Host-side builders of ConvArgs::hvtab / mtab for the box stored in `a`.
+void conv_build_tables(const ConvArgs &a, int MB, int *hvtab /*[conv_halo_voxels]*/, int *mtab /*[32*MB]*/);
+int conv_halo_voxels(const ConvArgs &a);
 // MB x NB = number of 32x32 accumulator blocks per wave (workgroup tile 32MB x 32NB).
 hipError_t launch_conv(const ConvArgs &a, int MB, int NB, hipStream_t st);
 bool conv_variant_exists(int MB, int NB);
+// Persistent, software-pipelined 3x3x3 kernel (cm_conv2.hip): MB x NB accumulator blocks
+// per wave (K split over the 4 waves), grid_x persistent workgroups pulling tiles from
+// ctr (zeroed int[2 * number of N tiles]).
+size_t conv2_lds_bytes(const ConvArgs &a, int MB, int NB);
+int conv2_nv(const ConvArgs &a);
+bool conv2_variant_exists(int MB, int NB, int NV);
+hipError_t launch_conv2(const ConvArgs &a, int MB, int NB, int grid_x, int *ctr, hipStream_t st);
 
 // ---- small kernels --------------------------------------------------------
 // Per-(sample, slice, channel) mean and M2 of a channels-last tensor.

@@ -84,7 +84,14 @@ struct Op {
   cm::ConvArgs ca{};
   int MB = 1, NB = 1;
   int tuned_B = -1;
+  int *d_hvtab = nullptr, *d_mtab = nullptr;  // device copies of the box coordinate tables
+  bool v2 = false;      // persistent M-split kernel (cm_conv2.hip)
+  int NW = 4, grid_x = 0;
+  int *d_ctr = nullptr; // its tile counters
   double flops_per_sample = 0;
+  std::string label;
+  double prof_ms = 0;
+  int64_t prof_n = 0;
   // stats
   const Act *act = nullptr;
   // gn finalize
@@ -351,6 +358,51 @@ void pick_tile(Op &op, int B) {
   op.tuned_B = B;
 }
 
+// Tile geometry for the persistent kernel (cm_conv2.hip): one sample per tile, MB row
+// blocks, halo image small enough for 2-3 workgroups per CU.
+void pick_tile2(Op &op, int B) {
+  cm::ConvArgs &a = op.ca;
+  const int NB = op.NB;
+  const int Zo = a.Zo, Yo = a.Yo, Xo = a.Xo;
+  const int vox = Zo * Yo * Xo;
+  const int ntn = (a.Co + 32 * NB - 1) / (32 * NB);
+  double best = -1;
+  int bbz = 1, bby = 1, bbx = 1, bMB = 0;
+  a.bs = 1;
+  for (int bz = 1; bz <= Zo; ++bz)
+    for (int by = 1; by <= Yo; ++by)
+      for (int bx = 1; bx <= Xo; ++bx) {
+        const int nbox = bz * by * bx;
+        const int MB = (nbox + 31) / 32;
+        if (MB > 4) continue;
+        a.bz = bz; a.by = by; a.bx = bx;
+        const int NV = cm::conv2_nv(a);
+        if (!NV || !cm::conv2_variant_exists(MB, NB, NV)) continue;
+        const size_t lds = cm::conv2_lds_bytes(a, MB, NB);
+        if (lds > 80 * 1024) continue;
+        const long ntz = (Zo + bz - 1) / bz, nty = (Yo + by - 1) / by, ntx = (Xo + bx - 1) / bx;
+        const double tiles = (double)ntz * nty * ntx * B * ntn;
+        const double util = (double)vox * B * ntn / (tiles * 32.0 * MB);
+        const int occ = std::max(1, std::min((int)(160 * 1024 / lds), 2));
+        const double per_cu = tiles / 256.0;
+        const double balance = (tiles <= 256.0 * occ) ? per_cu / std::ceil(per_cu - 1e-9) : per_cu / (per_cu + 0.5);
+        const double hv = (double)(bz + 2) * (by + 2) * (bx + 2);
+        const double halo = 1.0 / (1.0 + 0.02 * hv / (32.0 * MB));
+        const double amort = 1.0 - 0.08 / (MB * NB);
+        const double occf = occ >= 2 ? 1.0 : 0.85;
+        const double score = util * balance * halo * amort * occf;
+        if (score > best) { best = score; bbz = bz; bby = by; bbx = bx; bMB = MB; }
+      }
+  a.bz = bbz; a.by = bby; a.bx = bbx;
+  op.MB = bMB;
+  a.ntz = (Zo + bbz - 1) / bbz; a.nty = (Yo + bby - 1) / bby; a.ntx = (Xo + bbx - 1) / bbx;
+  const size_t lds = cm::conv2_lds_bytes(a, bMB, NB);
+  const int occ = std::max(1, std::min((int)(160 * 1024 / lds), 2));
+  const long tiles = (long)a.ntz * a.nty * a.ntx * B;
+  op.grid_x = (int)std::min<long>(tiles, 256L * occ);
+  op.tuned_B = B;
+}
+
 struct ConvSpec {
   const Act *s0;
   const Act *s1 = nullptr;
@@ -382,7 +434,14 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   a.CK = pick_ck(a.C0, a.C1);
   if (!a.CK) return fail("conv %s: channel counts %d/%d not multiples of 8", s.wname.c_str(), a.C0, a.C1);
   a.nch0 = a.C0 / a.CK; a.nch1 = a.C1 / a.CK;
+  // large-spatial 3x3x3 layers run on the persistent M-split kernel (all output
+  // channels per workgroup, up to 128); the K-split kernel keeps the rest
+  op.v2 = (s.ntaps == 27 && a.CK == 32 && s.stride == 1 && s.out->V() >= 128 && !getenv("CM_NO_CONV2"));
   op.NB = s.Co > 32 ? 2 : 1;
+  if (op.v2) {
+    if (dev_alloc(m, (void **)&op.d_ctr, 64 * sizeof(int))) return 1;
+    CM_HIP(hipMemset(op.d_ctr, 0, 64 * sizeof(int)));
+  }
   const Param &w = P(m, s.wname);
   const Param &b = P(m, s.bname);
   const int Ci_ref = (int)w.shape[1];
@@ -398,19 +457,20 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   if (upload(m, bp, &db)) return 1;
   a.wfrag = dw; a.bias = db;
   op.flops_per_sample = 2.0 * s.out->V() * s.Co * (double)Ci_ref * s.ntaps;
+  op.label = s.wname;
   m->ops.push_back(op);
   return 0;
 }
 
 void add_stats(cm_model *m, const Act *a) {
   Op op;
-  op.kind = OP_STATS; op.cls = K_NORM; op.act = a;
+  op.kind = OP_STATS; op.cls = K_NORM; op.act = a; op.label = "stats(" + a->name + ")";
   m->ops.push_back(op);
 }
 
 int add_gnfin(cm_model *m, const Act *g0, const Act *g1, const std::string &wname, const std::string &bname, float **gn_out) {
   Op op;
-  op.kind = OP_GNFIN; op.cls = K_NORM; op.g0 = g0; op.g1 = g1;
+  op.kind = OP_GNFIN; op.cls = K_NORM; op.g0 = g0; op.g1 = g1; op.label = "gn_finalize(" + wname + ")";
   float *dg = nullptr, *db = nullptr;
   if (upload(m, P(m, wname).host, &dg)) return 1;
   if (upload(m, P(m, bname).host, &db)) return 1;
@@ -499,7 +559,7 @@ int build_ops(cm_model *m) {
       if (add_conv(m, cq)) return 1;
       Act *ao = new_act(m, ap + ".core", b.cout, Zl[l], Yl[l], Xl[l], false, &rc);
       if (rc) return 1;
-      Op at; at.kind = OP_ATTN; at.cls = K_ATTN; at.qkv = qkv->d; at.aout = ao->d; at.S = qkv->V(); at.E = b.cout;
+      Op at; at.kind = OP_ATTN; at.cls = K_ATTN; at.label = ap + ".core"; at.qkv = qkv->d; at.aout = ao->d; at.S = qkv->V(); at.E = b.cout;
       if ((size_t)2 * at.S * (at.E / ATTN_HEADS) * 4 > 160 * 1024)
         return fail("attention with %d tokens exceeds the LDS-resident K/V design", at.S);
       m->ops.push_back(at);
@@ -612,7 +672,8 @@ int build_time_table(cm_model *m) {
 // forward
 // ------------------------------------------------------------------------------
 int run_ops(cm_model *m, int B, hipStream_t st) {
-  for (Op &op : m->ops) {
+  for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+    Op &op = m->ops[oi];
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->profile) {
       CM_HIP(hipEventCreate(&e0));
@@ -621,10 +682,26 @@ int run_ops(cm_model *m, int B, hipStream_t st) {
     }
     switch (op.kind) {
       case OP_CONV: {
-        if (op.tuned_B != B) pick_tile(op, B);
+        if (op.tuned_B != B) {
+          if (op.v2) pick_tile2(op, B);
+          else pick_tile(op, B);
+          std::vector<int> hv((size_t)cm::conv_halo_voxels(op.ca)), mt((size_t)32 * op.MB);
+          cm::conv_build_tables(op.ca, op.MB, hv.data(), mt.data());
+          if (!op.d_hvtab) {
+            if (dev_alloc(m, (void **)&op.d_hvtab, 16384 * sizeof(int))) return 1;
+            if (dev_alloc(m, (void **)&op.d_mtab, 256 * sizeof(int))) return 1;
+          }
+          if (hv.size() > 16384) return fail("halo box too large");
+          CM_HIP(hipMemcpyAsync(op.d_hvtab, hv.data(), hv.size() * sizeof(int), hipMemcpyHostToDevice, st));
+          CM_HIP(hipMemcpyAsync(op.d_mtab, mt.data(), mt.size() * sizeof(int), hipMemcpyHostToDevice, st));
+          CM_HIP(hipStreamSynchronize(st));
+          op.ca.hvtab = op.d_hvtab;
+          op.ca.mtab = op.d_mtab;
+        }
         op.ca.B = B;
         op.ca.nts = (B + op.ca.bs - 1) / op.ca.bs;
-        CM_HIP(cm::launch_conv(op.ca, op.MB, op.NB, st));
+        if (op.v2) CM_HIP(cm::launch_conv2(op.ca, op.MB, op.NB, op.grid_x, op.d_ctr, st));
+        else CM_HIP(cm::launch_conv(op.ca, op.MB, op.NB, st));
         break;
       }
       case OP_STATS:
@@ -642,7 +719,7 @@ int run_ops(cm_model *m, int B, hipStream_t st) {
     }
     if (m->profile) {
       CM_HIP(hipEventRecord(e1, st));
-      m->prof_events.push_back({op.cls, {e0, e1}});
+      m->prof_events.push_back({(int)oi, {e0, e1}});
     }
   }
   return 0;
@@ -651,6 +728,7 @@ int run_ops(cm_model *m, int B, hipStream_t st) {
 int prof_begin(cm_model *m) {
   if (!m->profile) return 0;
   for (int i = 0; i < K_NCLASS; ++i) { m->prof_ms[i] = 0; m->prof_n[i] = 0; }
+  for (Op &op : m->ops) { op.prof_ms = 0; op.prof_n = 0; }
   return 0;
 }
 
@@ -660,8 +738,11 @@ int prof_collect(cm_model *m, hipStream_t st) {
   for (auto &pe : m->prof_events) {
     float ms = 0;
     CM_HIP(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
-    m->prof_ms[pe.first] += ms;
-    m->prof_n[pe.first] += 1;
+    Op &op = m->ops[pe.first];
+    op.prof_ms += ms;
+    op.prof_n += 1;
+    m->prof_ms[op.cls] += ms;
+    m->prof_n[op.cls] += 1;
     hipEventDestroy(pe.second.first);
     hipEventDestroy(pe.second.second);
   }
@@ -1123,6 +1204,38 @@ int cm_model_cost(const cm_model *m, int32_t B, double *flops, double *bytes) {
   for (const Param &p : m->params) wbytes += 4.0 * p.numel();
   if (flops) *flops = f;
   if (bytes) *bytes = by + wbytes;
+  return 0;
+}
+
+int cm_profile_report(cm_model *m, char *buf, int64_t capacity) {
+  if (!m || !buf || capacity < 1) return fail("null argument");
+  std::string out;
+  char line[512];
+  for (const Op &op : m->ops) {
+    if (op.prof_n == 0) continue;
+    const double us = op.prof_ms * 1e3 / op.prof_n;
+    if (op.kind == OP_CONV) {
+      const cm::ConvArgs &a = op.ca;
+      const double tf = op.flops_per_sample * a.B / (us * 1e-6) / 1e12;
+      snprintf(line, sizeof(line), "%-52s %9.1f us %7.2f TF  %s%d NB%d box %dx%dx%dx%d grid %dx%d CK%d lds %zu\n", op.label.c_str(), us, tf,
+               op.v2 ? "v2 MB" : "MB", op.MB, op.NB, a.bs, a.bz, a.by, a.bx, op.v2 ? op.grid_x : a.nts * a.ntz * a.nty * a.ntx,
+               (a.Co + 32 * op.NB - 1) / (32 * op.NB), a.CK, op.v2 ? cm::conv2_lds_bytes(a, op.MB, op.NB) : cm::conv_lds_bytes(a, op.MB, op.NB));
+    } else {
+      snprintf(line, sizeof(line), "%-52s %9.1f us\n", op.label.c_str(), us);
+    }
+    out += line;
+  }
+  snprintf(buf, (size_t)capacity, "%s", out.c_str());
+  return 0;
+}
+
+int cm_model_class_flops(const cm_model *m, int32_t B, double flops[8]) {
+  if (!m || !m->finalized || !flops) return fail("model not finalized");
+  for (int i = 0; i < 8; ++i) flops[i] = 0;
+  for (const Op &op : m->ops) {
+    if (op.kind == OP_CONV) flops[op.cls] += op.flops_per_sample * B;
+    else if (op.kind == OP_ATTN) flops[op.cls] += 4.0 * op.S * (double)op.S * op.E * B;
+  }
   return 0;
 }
 

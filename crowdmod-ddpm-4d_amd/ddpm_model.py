@@ -96,10 +96,11 @@ class DDPM_model:
             hist = torch.empty((nsteps + 1,) + shape, device=dev, dtype=torch.float32) if history else None
             xt = x_T.contiguous().float() if x_T is not None else None
             nz = noise.contiguous().float() if noise is not None else None
-            st = torch.cuda.current_stream(dev).cuda_stream
+            torch.cuda.current_stream(dev).synchronize()   # inputs ready before the library's stream reads them
             native.check(L.cm_sample_loop(h, sampler_obj._handle, pst.data_ptr(), xt.data_ptr() if xt is not None else None,
                                           nz.data_ptr() if nz is not None else None, C.byref(opts), out.data_ptr(),
-                                          hist.data_ptr() if hist is not None else None, B, st))
+                                          hist.data_ptr() if hist is not None else None, B, None))
+            native.check(L.cm_device_synchronize(self.device))  # results complete on return
             if history:
                 return out, [hist[i] for i in range(nsteps + 1)]
             return out, None

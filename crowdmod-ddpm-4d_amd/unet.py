@@ -155,8 +155,11 @@ class UNet:
             pst = past.contiguous().float()
             tt = t.to(device=future.device, dtype=torch.long).contiguous()
             out = torch.empty_like(fut)
-            st = torch.cuda.current_stream(future.device).cuda_stream
-            native.check(L.cm_unet_forward(h, fut.data_ptr(), tt.data_ptr(), pst.data_ptr(), out.data_ptr(), B, st))
+            # the library runs on its own stream: order it after the producers of the
+            # inputs and hand back a finished result
+            torch.cuda.current_stream(future.device).synchronize()
+            native.check(L.cm_unet_forward(h, fut.data_ptr(), tt.data_ptr(), pst.data_ptr(), out.data_ptr(), B, None))
+            native.check(L.cm_device_synchronize(self.device))
             return out
         fut = np.ascontiguousarray(future, dtype=np.float32)
         pst = np.ascontiguousarray(past, dtype=np.float32)
@@ -182,3 +185,9 @@ class UNet:
         f, b = C.c_double(), C.c_double()
         native.check(native.lib().cm_model_cost(self._handle, B, C.byref(f), C.byref(b)))
         return f.value, b.value
+
+    def conv3_flops(self, B: int) -> float:
+        """Algorithmic FLOPs of the 3x3x3 convolutions of one forward at batch B."""
+        fl = (C.c_double * 8)()
+        native.check(native.lib().cm_model_class_flops(self._handle, B, fl))
+        return float(fl[0])

@@ -168,8 +168,12 @@ int cm_sample_num_steps(const cm_schedule *s, const cm_sample_opts *opts, int32_
  * 4 elementwise (assemble/step).  `ms` and `launches` hold 8 entries. */
 int cm_profile_enable(cm_model *m, int32_t on);
 int cm_profile_read(cm_model *m, float ms[8], int64_t launches[8]);
+/* Text table of the per-launch averages behind cm_profile_read (one line per op). */
+int cm_profile_report(cm_model *m, char *buf, int64_t capacity);
 /* Algorithmic FLOPs and bytes of one forward at batch B. */
 int cm_model_cost(const cm_model *m, int32_t B, double *flops, double *bytes);
+/* Algorithmic FLOPs of one forward per kernel class (same indices as cm_profile_read). */
+int cm_model_class_flops(const cm_model *m, int32_t B, double flops[8]);
 
 #ifdef __cplusplus
 }
