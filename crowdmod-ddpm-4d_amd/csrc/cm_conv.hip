@@ -31,7 +31,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division sequence
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-template <int MB, int NB, bool FAST>
+// FAST = 0: generic step loop; 27 / 8: CK == 32 with that many taps (register weight ring)
+template <int MB, int NB, int FAST>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TM = 32 * MB;
@@ -64,10 +65,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   }
   const int b0 = ts * a.bs, z0 = tz * a.bz, y0 = ty * a.by, x0 = tx * a.bx;
 
-  const int pad = (a.ntaps == 27) ? 1 : 0;
-  const int HZ = (a.bz - 1) * a.stride + 1 + 2 * pad;
-  const int HY = (a.by - 1) * a.stride + 1 + 2 * pad;
-  const int HX = (a.bx - 1) * a.stride + 1 + 2 * pad;
+  // parity class of an upsampled conv: out voxel u = 2i + p reads source voxels i + e + p - 1,
+  // e in {0,1}, with the taps that fall on the same source voxel pre-summed on the host
+  const int par = a.par ? (int)blockIdx.z : 0;
+  const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
+  const int os = a.par ? 2 : 1;
+  const int pad = (a.td == 3) ? 1 : 0;
+  const int td = a.td;
+  const int HZ = (a.bz - 1) * a.stride + td;
+  const int HY = (a.by - 1) * a.stride + td;
+  const int HX = (a.bx - 1) * a.stride + td;
   const int HV1 = HZ * HY * HX;
   const int HV = a.bs * HV1;
   const int HVp = (HV + 3) & ~3;
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     int off = -1, bb = 0;
     if (pk >= 0) {
       const int x = pk & 511, y = (pk >> 9) & 511, z = (pk >> 18) & 255, s = pk >> 26;
-      const int b = b0 + s, oz = z0 + z, oy = y0 + y, ox = x0 + x;
+      const int b = b0 + s, oz = os * (z0 + z) + pz, oy = os * (y0 + y) + py, ox = os * (x0 + x) + px;
       bb = b < a.B ? b : 0;
       if (b < a.B && oz < a.Zo && oy < a.Yo && ox < a.Xo) off = ((b * a.Zo + oz) * a.Yo + oy) * a.Xo + ox;
     }
@@ -93,7 +100,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     outb[m] = bb;
   }
   const int Zc = a.Zs << a.ups, Yc = a.Ys << a.ups, Xc = a.Xs << a.ups;
-  const int cz0 = z0 * a.stride - pad, cy0 = y0 * a.stride - pad, cx0 = x0 * a.stride - pad;
+  const int cz0 = z0 * a.stride + (a.par ? pz - 1 : -pad), cy0 = y0 * a.stride + (a.par ? py - 1 : -pad),
+            cx0 = x0 * a.stride + (a.par ? px - 1 : -pad);
 
   // ---- per-lane LDS row base of each of this wave's MB row blocks -----------
   int abase[MB];
@@ -120,12 +128,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int nsteps = a.ntaps * K8;
   const int nchunks = a.nch0 + a.nch1;
   const int Ctot = a.C0 + a.C1;
-  const f32x4 *wtile = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * nchunks * nsteps * NB * 64 + lane;
+  const f32x4 *wtile = reinterpret_cast<const f32x4 *>(a.wfrag + (size_t)par * a.wpar_stride) +
+                       (size_t)nt * nchunks * nsteps * NB * 64 + lane;
 
   const int q4 = tid % K4, v0 = tid / K4, vstep = 256 / K4;
 
-  constexpr int PD = 3;  // weight prefetch depth of the fast path (steps)
-  constexpr bool fast = FAST;  // host guarantees CK == 32 && ntaps == 27
+  constexpr bool fast = FAST != 0;           // host guarantees CK == 32 && ntaps == FAST
+  constexpr int TAPS = FAST ? FAST : 27;
+  constexpr int PD = (TAPS == 27) ? 3 : 2;   // weight prefetch depth of the fast path (taps), TAPS % PD == 0
   f32x4 bq[PD][NB];
   if constexpr (fast) {
 #pragma unroll
@@ -195,11 +205,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       // continues across chunk boundaries, so neither the L2 latency nor the staging
       // barrier exposes a weight load.
 #pragma unroll 1
-      for (int i0 = 0; i0 < 27; i0 += PD) {
+      for (int i0 = 0; i0 < TAPS; i0 += PD) {
 #pragma unroll
         for (int d = 0; d < PD; ++d) {
           const int t = i0 + d;  // tap index
-          const int dz = t / 9, rem = t - dz * 9, dy = rem / 3, dx = rem - dy * 3;
+          int dz, dy, dx;
+          if constexpr (TAPS == 27) { dz = t / 9; const int rem = t - dz * 9; dy = rem / 3; dx = rem - dy * 3; }
+          else { dz = t >> 2; dy = (t >> 1) & 1; dx = t & 1; }
           const int aoff = ((dz * HY + dy) * HX + dx) * S + wave * 8;
           f32x4 af[MB];
 #pragma unroll
@@ -211,11 +223,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
               for (int nb = 0; nb < NB; ++nb)
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mb][jj], bq[d][nb][jj], acc[mb][nb], 0, 0, 0);
-          // refill this ring slot with the fragments PD steps ahead (possibly next chunk)
+          // refill this ring slot with the fragments PD taps ahead (possibly next chunk)
           int tn = t + PD, chn = ch;
-          if (tn >= 27) { tn -= 27; chn += 1; }
+          if (tn >= TAPS) { tn -= TAPS; chn += 1; }
           if (chn < nchunks) {
-            const f32x4 *wp = wtile + ((size_t)chn * 108 + (wave + 4 * tn)) * NB * 64;
+            const f32x4 *wp = wtile + ((size_t)chn * (TAPS * 4) + (wave + 4 * tn)) * NB * 64;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) bq[d][nb] = wp[nb * 64];
           }
@@ -231,8 +243,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       for (int s = wave; s < nsteps; s += 4) {
         const int t = s / K8, j = s - t * K8;
         int tapoff = 0;
-        if (a.ntaps == 27) {
-          const int dz = t / 9, rem = t - dz * 9, dy = rem / 3, dx = rem - dy * 3;
+        if (td > 1) {
+          const int dz = t / (td * td), rem = t - dz * td * td, dy = rem / td, dx = rem - dy * td;
           tapoff = (dz * HY + dy) * HX + dx;
         }
         const int aoff = tapoff * S + j * 8;
@@ -330,6 +342,29 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg)
             if (nok && offs[reg] >= 0) a.out[(size_t)offs[reg] * a.out_cs + n] = rs[reg];
+          if (a.stat_part) {
+            // fused GroupNorm statistics of this 32-row block (two-pass on registers, the
+            // two lane halves merged with one cross-lane exchange): layers.py:30,41 read them
+            float s1 = 0.f, cnt = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+              if (offs[reg] >= 0) { s1 += rs[reg]; cnt += 1.f; }
+            s1 += __shfl_xor(s1, 32);
+            cnt += __shfl_xor(cnt, 32);
+            const float mean = cnt > 0.f ? s1 / cnt : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+              if (offs[reg] >= 0) { const float d = rs[reg] - mean; q += d * d; }
+            q += __shfl_xor(q, 32);
+            const int slot = ((par * a.ntz + tz) * a.nty + ty) * a.ntx * MB + tx * MB + mb;
+            if (h == 0 && nok && b0 < a.B) {
+              float *sp = a.stat_part + (((size_t)b0 * a.stat_ns + slot) * a.stat_C + n) * 2;
+              sp[0] = mean;
+              sp[1] = q;
+            }
+            if (lane == 0 && n == 0 && b0 < a.B) a.stat_cnt[(size_t)b0 * a.stat_ns + slot] = cnt;
+          }
         }
       }
     }
@@ -337,10 +372,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 }
 
 size_t conv_lds_bytes(const ConvArgs &a, int MB, int NB) {
-  const int pad = (a.ntaps == 27) ? 1 : 0;
-  const int HZ = (a.bz - 1) * a.stride + 1 + 2 * pad;
-  const int HY = (a.by - 1) * a.stride + 1 + 2 * pad;
-  const int HX = (a.bx - 1) * a.stride + 1 + 2 * pad;
+  const int HZ = (a.bz - 1) * a.stride + a.td;
+  const int HY = (a.by - 1) * a.stride + a.td;
+  const int HX = (a.bx - 1) * a.stride + a.td;
   const int HV = a.bs * HZ * HY * HX;
   const int HVp = (HV + 3) & ~3;
   const int S = a.CK + 4;
@@ -354,18 +388,16 @@ size_t conv_lds_bytes(const ConvArgs &a, int MB, int NB) {
 }
 
 int conv_halo_voxels(const ConvArgs &a) {
-  const int pad = (a.ntaps == 27) ? 1 : 0;
-  const int HZ = (a.bz - 1) * a.stride + 1 + 2 * pad;
-  const int HY = (a.by - 1) * a.stride + 1 + 2 * pad;
-  const int HX = (a.bx - 1) * a.stride + 1 + 2 * pad;
+  const int HZ = (a.bz - 1) * a.stride + a.td;
+  const int HY = (a.by - 1) * a.stride + a.td;
+  const int HX = (a.bx - 1) * a.stride + a.td;
   return a.bs * HZ * HY * HX;
 }
 
 void conv_build_tables(const ConvArgs &a, int MB, int *hvtab, int *mtab) {
-  const int pad = (a.ntaps == 27) ? 1 : 0;
-  const int HZ = (a.bz - 1) * a.stride + 1 + 2 * pad;
-  const int HY = (a.by - 1) * a.stride + 1 + 2 * pad;
-  const int HX = (a.bx - 1) * a.stride + 1 + 2 * pad;
+  const int HZ = (a.bz - 1) * a.stride + a.td;
+  const int HY = (a.by - 1) * a.stride + a.td;
+  const int HX = (a.bx - 1) * a.stride + a.td;
   int i = 0;
   for (int s = 0; s < a.bs; ++s)
     for (int hz = 0; hz < HZ; ++hz)
@@ -404,34 +436,27 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
   const size_t lds = conv_lds_bytes(a, MB, NB);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int TN = 32 * NB;
-  dim3 grid((unsigned)(a.nts * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + TN - 1) / TN));
-  const bool fast = (a.CK == 32 && a.ntaps == 27);
-#define X(m, n)                                                                              \
-  if (MB == m && NB == n && fast) {                                                          \
-    static bool attr_set[64] = {false};                                                      \
-    int dev = 0;                                                                             \
-    (void)hipGetDevice(&dev);                                                                \
-    if (!attr_set[dev & 63]) {                                                               \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<m, n, true>), \
+  dim3 grid((unsigned)(a.nts * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + TN - 1) / TN), a.par ? 8u : 1u);
+  const int fastk = (a.CK == 32 && (a.ntaps == 27 || a.ntaps == 8)) ? a.ntaps : 0;
+#define CM_LAUNCH(m, n, f)                                                                       \
+  {                                                                                              \
+    static bool attr_set[64] = {false};                                                          \
+    int dev = 0;                                                                                 \
+    (void)hipGetDevice(&dev);                                                                    \
+    if (!attr_set[dev & 63]) {                                                                   \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<m, n, f>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      if (e != hipSuccess) return e;                                                         \
-      attr_set[dev & 63] = true;                                                             \
-    }                                                                                        \
-    hipLaunchKernelGGL((conv_mfma_kernel<m, n, true>), grid, dim3(256), lds, st, a);           \
-    return hipGetLastError();                                                                \
-  }                                                                                          \
-  if (MB == m && NB == n) {                                                                  \
-    static bool attr_set[64] = {false};                                                      \
-    int dev = 0;                                                                             \
-    (void)hipGetDevice(&dev);                                                                \
-    if (!attr_set[dev & 63]) {                                                               \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<m, n, false>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      if (e != hipSuccess) return e;                                                         \
-      attr_set[dev & 63] = true;                                                             \
-    }                                                                                        \
-    hipLaunchKernelGGL((conv_mfma_kernel<m, n, false>), grid, dim3(256), lds, st, a);          \
-    return hipGetLastError();                                                                \
+      if (e != hipSuccess) return e;                                                             \
+      attr_set[dev & 63] = true;                                                                 \
+    }                                                                                            \
+    hipLaunchKernelGGL((conv_mfma_kernel<m, n, f>), grid, dim3(256), lds, st, a);                \
+    return hipGetLastError();                                                                    \
+  }
+#define X(m, n)                                    \
+  if (MB == m && NB == n) {                        \
+    if (fastk == 27) CM_LAUNCH(m, n, 27)           \
+    if (fastk == 8) CM_LAUNCH(m, n, 8)             \
+    CM_LAUNCH(m, n, 0)                             \
   }
   CM_CONV_VARIANTS(X)
 #undef X

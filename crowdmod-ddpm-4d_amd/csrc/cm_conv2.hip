@@ -340,6 +340,29 @@ __global__ __launch_bounds__(256, 2) void conv3_persist_kernel(const ConvArgs a,
 #pragma unroll
               for (int reg = 0; reg < 16; ++reg)
                 if (nok && offs[reg] >= 0) a.out[(size_t)offs[reg] * a.out_cs + n] = rs[reg];
+              if (a.stat_part) {
+                // fused GroupNorm statistics of this 32-row block (see cm_conv.hip)
+                float s1 = 0.f, cnt = 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                  if (offs[reg] >= 0) { s1 += rs[reg]; cnt += 1.f; }
+                s1 += __shfl_xor(s1, 32);
+                cnt += __shfl_xor(cnt, 32);
+                const float mean = cnt > 0.f ? s1 / cnt : 0.f;
+                float q = 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                  if (offs[reg] >= 0) { const float d = rs[reg] - mean; q += d * d; }
+                q += __shfl_xor(q, 32);
+                const int tps = a.ntz * a.nty * a.ntx;
+                const int sb = cur / tps, slot = (cur - sb * tps) * MB + mb;
+                if (h == 0 && nok) {
+                  float *sp = a.stat_part + (((size_t)sb * a.stat_ns + slot) * a.stat_C + n) * 2;
+                  sp[0] = mean;
+                  sp[1] = q;
+                }
+                if (lane == 0 && n == 0) a.stat_cnt[(size_t)sb * a.stat_ns + slot] = cnt;
+              }
             }
           }
         }
@@ -366,8 +389,8 @@ __global__ __launch_bounds__(256, 2) void conv3_persist_kernel(const ConvArgs a,
     else { cur = nxt; nxt = nn; ch = 0; }
   }
 
-  if ((a.dbg & 8) && tid == 0 && a.stat_part) {
-    for (int i = 0; i < 8; ++i) a.stat_part[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + i] = (float)tph[i];
+  if ((a.dbg & 8) && tid == 0 && a.dbg_buf) {
+    for (int i = 0; i < 8; ++i) a.dbg_buf[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + i] = (float)tph[i];
   }
   // ---- the last workgroup to finish re-arms the counter for the next launch --------
   if (tid == 0) {
@@ -413,7 +436,7 @@ hipError_t launch_conv2(const ConvArgs &a_in, int MB, int NB, int grid_x, int *c
   static float *dbgbuf = nullptr;
   if (dbg & 8) {
     if (!dbgbuf) (void)hipMalloc((void **)&dbgbuf, 4096 * 8 * sizeof(float));
-    a.stat_part = dbgbuf;
+    a.dbg_buf = dbgbuf;
   }
   if (a.ntaps != 27 || a.CK != 32 || a.stride != 1 || a.bs != 1) return hipErrorInvalidValue;
   const int NV = conv2_nv(a);

@@ -33,7 +33,11 @@ struct ConvArgs {
   int B;
   int Zs, Ys, Xs;      // source dims (before nearest-upsample)
   int Zo, Yo, Xo;      // output dims
-  int ntaps;           // 27 (3x3x3, zero pad 1) or 1 (1x1x1)
+  int ntaps;           // td^3: 27 (3x3x3, zero pad 1), 8 (parity sub-kernel of an upsampled conv) or 1
+  int td;              // taps per dimension: 3, 2 or 1
+  int par;             // 1: nearest-x2-upsample + 3x3x3 conv evaluated as 8 parity classes of 2x2x2
+                       //    convs on the low-resolution source (gridDim.z = 8); output voxel = 2*i + parity
+  long long wpar_stride;  // floats between the packed weight sets of consecutive parities
   int stride;          // 1 or 2
   int ups;             // 1: source is nearest-upsampled x2 on the fly
   int bs, bz, by, bx;  // output box of one workgroup: samples x z x y x x
@@ -42,8 +46,14 @@ struct ConvArgs {
   int nch0, nch1;      // chunks in src0 / src1
   const int *hvtab;    // [HV] packed halo-box coordinates  s<<26 | hz<<18 | hy<<9 | hx  (host-built)
   const int *mtab;     // [32*MB] packed output-box coordinates s<<26 | z<<18 | y<<9 | x, or -1 (padding row)
-  float *stat_part;    // optional fused per-channel statistics partials (unused in v1)
+  // fused GroupNorm statistics of the OUTPUT (one sample per tile required): every 32-row
+  // accumulator block writes (mean, M2) per channel to stat_part[b][slot][stat_C][2] and its
+  // row count to stat_cnt[b][slot], slot = tile_in_sample * MB + mb, stat_ns slots per sample
+  float *stat_part;
+  float *stat_cnt;
+  int stat_C, stat_ns;
   int dbg;             // ablation switches for performance studies (0 in production)
+  float *dbg_buf;      // cycle-stamp sink of the diagnostic build paths
   int stagger;         // start delay (in 64-cycle units) applied to every other first-wave workgroup
 };
 
@@ -65,12 +75,13 @@ hipError_t launch_conv2(const ConvArgs &a, int MB, int NB, int grid_x, int *ctr,
 // ---- small kernels --------------------------------------------------------
 // Per-(sample, slice, channel) mean and M2 of a channels-last tensor.
 //   part [B][nslice][C][2]
-hipError_t launch_chan_stats(const float *x, int B, int V, int C, int nslice, float *part, hipStream_t st);
-// Combine partial statistics of (up to) two concatenated tensors into GroupNorm
-// scale/shift rows:  gn[b][0][c] = rstd_g*gamma_c ; gn[b][1][c] = beta_c - mean_g*rstd_g*gamma_c
-hipError_t launch_gn_finalize(const float *part0, int C0, const float *part1, int C1, int nslice, int V,
-                              const float *gamma, const float *beta, int groups, float eps, float *gn, int B,
-                              hipStream_t st);
+hipError_t launch_chan_stats(const float *x, int B, int V, int C, int nslice, float *part, float *cnt, hipStream_t st);
+// Combine partial statistics (per slot: mean, M2 in part[b][slot][C][2], row count in
+// cnt[b][slot]) of (up to) two concatenated tensors into GroupNorm scale/shift rows:
+//   gn[b][0][c] = rstd_g*gamma_c ; gn[b][1][c] = beta_c - mean_g*rstd_g*gamma_c
+hipError_t launch_gn_finalize(const float *part0, const float *cnt0, int ns0, int C0, const float *part1,
+                              const float *cnt1, int ns1, int C1, int V, const float *gamma, const float *beta,
+                              int groups, float eps, float *gn, int B, hipStream_t st);
 // reference layout [B,C,H,W,P] + [B,C,H,W,F]  ->  channels-last [B][P+F][H][W][8]
 hipError_t launch_assemble_input(const float *past, const float *future, float *x8, int B, int C, int H, int W,
                                  int P, int F, int which /*1 past,2 future,3 both*/, hipStream_t st);

@@ -29,7 +29,7 @@ __device__ __forceinline__ void chan_combine(float &n, float &mean, float &m2, f
 // threads are merged with Chan's formula through LDS in a fixed order.
 // --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void chan_stats_kernel(const float *__restrict__ x, int V, int C, int nslice,
-                                                         float *__restrict__ part) {
+                                                         float *__restrict__ part, float *__restrict__ cnt) {
   __shared__ float sh[256 * 4 * 3];
   const int b = blockIdx.y, sl = blockIdx.x;
   const int Q = C >> 2;                 // channel quads
@@ -82,11 +82,13 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const float *__restrict
     p[0] = M;
     p[1] = S2;
   }
+  if (tid == 0) cnt[(size_t)b * nslice + sl] = (float)max(0, vend - vbeg);
 }
 
-hipError_t launch_chan_stats(const float *x, int B, int V, int C, int nslice, float *part, hipStream_t st) {
+hipError_t launch_chan_stats(const float *x, int B, int V, int C, int nslice, float *part, float *cnt,
+                             hipStream_t st) {
   if (C % 4 != 0 || C / 4 > 256) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(chan_stats_kernel, dim3(nslice, B), dim3(256), 0, st, x, V, C, nslice, part);
+  hipLaunchKernelGGL(chan_stats_kernel, dim3(nslice, B), dim3(256), 0, st, x, V, C, nslice, part, cnt);
   return hipGetLastError();
 }
 
@@ -96,27 +98,39 @@ hipError_t launch_chan_stats(const float *x, int B, int V, int C, int nslice, fl
 // folded with the affine into one scale/shift pair per (sample, channel).
 // grid B, 256 threads.
 // --------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ p0, int C0,
-                                                          const float *__restrict__ p1, int C1, int nslice, int V,
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ p0, const float *__restrict__ n0,
+                                                          int ns0, int C0, const float *__restrict__ p1,
+                                                          const float *__restrict__ n1, int ns1, int C1, int V,
                                                           const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, int groups, float eps,
                                                           float *__restrict__ gn) {
-  extern __shared__ float sm[];  // [Ctot] mean, [Ctot] m2, [groups] gmean, [groups] grstd
+  // sm: [nl][Ct][3] partial triples, then [Ct] mean, [Ct] m2, [groups] gmean, [groups] grstd
+  extern __shared__ float sm[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int Ct = C0 + C1;
-  float *cmean = sm, *cm2 = sm + Ct, *gmean = sm + 2 * Ct, *grstd = gmean + groups;
-  const int vs = (V + nslice - 1) / nslice;
-  for (int c = tid; c < Ct; c += 256) {
-    const float *p;
-    int Cx, cc;
-    if (c < C0) { p = p0; Cx = C0; cc = c; } else { p = p1; Cx = C1; cc = c - C0; }
+  const int nl = max(1, 256 / Ct);  // slot lanes per channel
+  float *tri = sm;
+  float *cmean = sm + (size_t)nl * Ct * 3, *cm2 = cmean + Ct, *gmean = cm2 + Ct, *grstd = gmean + groups;
+  // stage 1: thread (channel c, lane j) merges the slots j, j+nl, ... of its channel in order
+  for (int idx = tid; idx < nl * Ct; idx += 256) {
+    const int c = idx % Ct, j = idx / Ct;
+    const float *p, *nn;
+    int Cx, cc, ns;
+    if (c < C0) { p = p0; nn = n0; Cx = C0; cc = c; ns = ns0; } else { p = p1; nn = n1; Cx = C1; cc = c - C0; ns = ns1; }
     float N = 0.f, M = 0.f, S2 = 0.f;
-    for (int s = 0; s < nslice; ++s) {
-      const int cnt = min(V, (s + 1) * vs) - s * vs;
-      if (cnt <= 0) break;
-      const float *q = p + (((size_t)b * nslice + s) * Cx + cc) * 2;
-      chan_combine(N, M, S2, (float)cnt, q[0], q[1]);
+    for (int s = j; s < ns; s += nl) {
+      const float cnt = nn[(size_t)b * ns + s];
+      const float *q = p + (((size_t)b * ns + s) * Cx + cc) * 2;
+      chan_combine(N, M, S2, cnt, q[0], q[1]);
     }
+    tri[(j * Ct + c) * 3 + 0] = N;
+    tri[(j * Ct + c) * 3 + 1] = M;
+    tri[(j * Ct + c) * 3 + 2] = S2;
+  }
+  __syncthreads();
+  for (int c = tid; c < Ct; c += 256) {
+    float N = 0.f, M = 0.f, S2 = 0.f;
+    for (int j = 0; j < nl; ++j) chan_combine(N, M, S2, tri[(j * Ct + c) * 3], tri[(j * Ct + c) * 3 + 1], tri[(j * Ct + c) * 3 + 2]);
     cmean[c] = M;
     cm2[c] = S2;
   }
@@ -137,14 +151,15 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
   }
 }
 
-hipError_t launch_gn_finalize(const float *part0, int C0, const float *part1, int C1, int nslice, int V,
-                              const float *gamma, const float *beta, int groups, float eps, float *gn, int B,
-                              hipStream_t st) {
+hipError_t launch_gn_finalize(const float *part0, const float *cnt0, int ns0, int C0, const float *part1,
+                              const float *cnt1, int ns1, int C1, int V, const float *gamma, const float *beta,
+                              int groups, float eps, float *gn, int B, hipStream_t st) {
   const int Ct = C0 + C1;
   if (Ct % groups != 0) return hipErrorInvalidValue;
-  const size_t smem = (size_t)(2 * Ct + 2 * groups) * sizeof(float);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), smem, st, part0, C0, part1, C1, nslice, V, gamma, beta,
-                     groups, eps, gn);
+  const int nl = 256 / Ct > 0 ? 256 / Ct : 1;
+  const size_t smem = ((size_t)nl * Ct * 3 + 2 * Ct + 2 * groups) * sizeof(float);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), smem, st, part0, cnt0, ns0, C0, part1, cnt1, ns1, C1, V,
+                     gamma, beta, groups, eps, gn);
   return hipGetLastError();
 }
 

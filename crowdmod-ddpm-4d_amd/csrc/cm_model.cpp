@@ -44,6 +44,7 @@ constexpr float GN_EPS = 1e-5f;
 constexpr int ATTN_HEADS = 4;      // layers.py:10
 constexpr int TIME_ROWS = 1000;    // embeddings.py:7
 constexpr int MAX_SLICES = 16;
+constexpr int MAX_SLOTS = 512;  // statistics slots per sample (32-row accumulator blocks of a conv)
 
 enum KClass { K_CONV3 = 0, K_CONV1 = 1, K_NORM = 2, K_ATTN = 3, K_ELEM = 4, K_NCLASS = 8 };
 
@@ -64,8 +65,10 @@ struct Act {
   std::string name;
   float *d = nullptr;
   int C = 0, Z = 0, Y = 0, X = 0;
-  float *part = nullptr;  // [B][nslice][C][2]
-  int nslice = 1;
+  float *part = nullptr;  // [B][nslots][C][2] per-slot (mean, M2) of every channel
+  float *cnt = nullptr;   // [B][nslots] rows behind each slot
+  int nslice = 1;         // slots when the stand-alone statistics kernel fills them
+  int nslots = 0;         // slots of the last producer (fused conv epilogue or stats kernel)
   int V() const { return Z * Y * X; }
 };
 
@@ -85,7 +88,8 @@ struct Op {
   int MB = 1, NB = 1;
   int tuned_B = -1;
   int *d_hvtab = nullptr, *d_mtab = nullptr;  // device copies of the box coordinate tables
-  bool v2 = false;      // persistent M-split kernel (cm_conv2.hip)
+  Act *stat_act = nullptr;  // output tensor whose GroupNorm statistics this conv produces in its epilogue
+  bool v2 = false;      // persistent pipelined kernel (cm_conv2.hip)
   int NW = 4, grid_x = 0;
   int *d_ctr = nullptr; // its tile counters
   double flops_per_sample = 0;
@@ -271,7 +275,8 @@ Act *new_act(cm_model *m, const std::string &name, int C, int Z, int Y, int X, b
   if (dev_alloc(m, (void **)&a->d, B * a->V() * C * sizeof(float))) { *rc = 1; return nullptr; }
   if (stats) {
     a->nslice = std::max(1, std::min(MAX_SLICES, a->V() / 128));
-    if (dev_alloc(m, (void **)&a->part, B * a->nslice * C * 2 * sizeof(float))) { *rc = 1; return nullptr; }
+    if (dev_alloc(m, (void **)&a->part, B * MAX_SLOTS * C * 2 * sizeof(float))) { *rc = 1; return nullptr; }
+    if (dev_alloc(m, (void **)&a->cnt, B * MAX_SLOTS * sizeof(float))) { *rc = 1; return nullptr; }
   }
   Act *r = a.get();
   m->acts.push_back(std::move(a));
@@ -288,6 +293,42 @@ const Param &P(const cm_model *m, const std::string &name) { return m->params[m-
 // with internal tap (dz,dy,dx) = reference [kH=dy][kW=dx][kL=dz]; zero beyond Co / Ci.
 // One wave-load of a step is 64 lanes x 16 B = 1 KiB contiguous.
 // ------------------------------------------------------------------------------
+// Reference conv weight [Co][Ci][kH][kW][kL] -> internal tap order [Co][Ci][t], t = (dz*3 + dy)*3 + dx
+// with (dz,dy,dx) = (kL,kH,kW)  (the internal layout is [Z=frames][Y=rows][X=cols]).
+std::vector<float> to_internal_taps(const float *W, int Co, int Ci, int ntaps) {
+  std::vector<float> out((size_t)Co * Ci * ntaps);
+  for (size_t cc = 0; cc < (size_t)Co * Ci; ++cc)
+    for (int t = 0; t < ntaps; ++t) {
+      const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+      const int tap_ref = (ntaps == 27) ? (dy * 3 + dx) * 3 + dz : 0;
+      out[cc * ntaps + t] = W[cc * ntaps + tap_ref];
+    }
+  return out;
+}
+
+// nn.Upsample(x2, nearest) followed by a 3x3x3 conv (layers.py:93-94) collapses, for each
+// parity p of the output voxel u = 2i + p, to a 2x2x2 conv over source voxels i + e + p - 1:
+// along one axis tap d of the upsampled grid reads source floor((2i + p + d - 1)/2), i.e.
+//   p = 0: d=0 -> i-1 (e=0), d=1,2 -> i (e=1);    p = 1: d=0,1 -> i (e=0), d=2 -> i+1 (e=1).
+// Taps that land on the same source voxel are summed here (in double, rounded once).
+// in: internal order [Co][Ci][27]; out: [8 parities][Co][Ci][8], e index = (ez*2 + ey)*2 + ex.
+std::vector<float> parity_weights(const std::vector<float> &Wi, int Co, int Ci) {
+  std::vector<float> out((size_t)8 * Co * Ci * 8, 0.f);
+  auto emap = [](int p, int d) { return p == 0 ? (d == 0 ? 0 : 1) : (d == 2 ? 1 : 0); };
+  for (int p = 0; p < 8; ++p) {
+    const int pz = (p >> 2) & 1, py = (p >> 1) & 1, px = p & 1;
+    for (size_t cc = 0; cc < (size_t)Co * Ci; ++cc) {
+      double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int dz = 0; dz < 3; ++dz)
+        for (int dy = 0; dy < 3; ++dy)
+          for (int dx = 0; dx < 3; ++dx)
+            acc[(emap(pz, dz) * 2 + emap(py, dy)) * 2 + emap(px, dx)] += (double)Wi[cc * 27 + (dz * 3 + dy) * 3 + dx];
+      for (int e = 0; e < 8; ++e) out[((size_t)p * Co * Ci + cc) * 8 + e] = (float)acc[e];
+    }
+  }
+  return out;
+}
+
 std::vector<float> pack_conv_weights(const float *W, int Co, int Ci, int ntaps, int Ci_pad, int CK, int NB) {
   const int TN = 32 * NB, ntn = (Co + TN - 1) / TN, nch = Ci_pad / CK, K8 = CK / 8, nsteps = ntaps * K8;
   std::vector<float> out((size_t)ntn * nch * nsteps * NB * 64 * 4, 0.f);
@@ -296,14 +337,12 @@ std::vector<float> pack_conv_weights(const float *W, int Co, int Ci, int ntaps, 
     for (int ch = 0; ch < nch; ++ch)
       for (int s = 0; s < nsteps; ++s) {
         const int t = s / K8, j = s % K8;
-        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
-        const int tap_ref = (ntaps == 27) ? (dy * 3 + dx) * 3 + dz : 0;
         for (int nb = 0; nb < NB; ++nb)
           for (int lane = 0; lane < 64; ++lane)
             for (int jj = 0; jj < 4; ++jj, ++o) {
               const int co = nt * TN + nb * 32 + (lane & 31);
               const int ci = ch * CK + 8 * j + 4 * (lane >> 5) + jj;
-              if (co < Co && ci < Ci) out[o] = W[((size_t)co * Ci + ci) * ntaps + tap_ref];
+              if (co < Co && ci < Ci) out[o] = W[((size_t)co * Ci + ci) * ntaps + t];
             }
       }
   return out;
@@ -317,35 +356,44 @@ int pick_ck(int C0, int C1) {
 
 // Tile geometry for one conv at batch B: choose the output box (bs,bz,by,bx) and
 // the per-wave accumulator blocking MB (NB is fixed by the packed weights).
+// Tile geometry is chosen for a fixed reference batch, never for the batch at hand: the
+// fused GroupNorm statistics are summed per tile, so a geometry that changed with the
+// batch size would make sample i of a shard differ in the last bits from sample i of the
+// unsharded batch (SURVEY.md section 8e asks for bit-identical shards).
+constexpr int TUNE_BATCH = 64;
+
 void pick_tile(Op &op, int B) {
   cm::ConvArgs &a = op.ca;
   const int NB = op.NB;
-  const int Zo = a.Zo, Yo = a.Yo, Xo = a.Xo;
+  static const int force_mb = getenv("CM_FORCE_MB") ? atoi(getenv("CM_FORCE_MB")) : 0;
+  const int osd = a.par ? 2 : 1;  // parity mode tiles the low-resolution source grid
+  const int Zo = a.Zo / osd, Yo = a.Yo / osd, Xo = a.Xo / osd;
   const int vox = Zo * Yo * Xo;
   const int max_blk = (NB == 1) ? 8 : (NB == 2 ? 4 : 2);
   double best = -1;
   int bbs = 1, bbz = 1, bby = 1, bbx = 1, bMB = 1;
   const int ntn = (a.Co + 32 * NB - 1) / (32 * NB);
-  for (int bs = 1; bs <= (vox <= 64 ? 4 : 1); ++bs)
+  const int max_bs = (vox <= 64 && !op.stat_act) ? 4 : 1;  // fused statistics need one sample per tile
+  for (int bs = 1; bs <= max_bs; ++bs)
     for (int bz = 1; bz <= Zo; ++bz)
       for (int by = 1; by <= Yo; ++by)
         for (int bx = 1; bx <= Xo; ++bx) {
           const int nbox = bs * bz * by * bx;
           const int MB = (nbox + 31) / 32;
           if (MB > max_blk) continue;
+          if (force_mb && MB != force_mb && vox >= 128) continue;
           a.bs = bs; a.bz = bz; a.by = by; a.bx = bx;
           const size_t lds = cm::conv_lds_bytes(a, MB, NB);
           if (lds > 64 * 1024) continue;
           const long ntz = (Zo + bz - 1) / bz, nty = (Yo + by - 1) / by, ntx = (Xo + bx - 1) / bx, nts = (B + bs - 1) / bs;
-          const double tiles = (double)ntz * nty * ntx * nts * ntn;
+          const double tiles = (double)ntz * nty * ntx * nts * ntn * (a.par ? 8 : 1);
           const double util = (double)vox * B * ntn / (tiles * 32.0 * MB);
           // work per tile in accumulator blocks; balance over 256 CUs
           const double per_cu = std::ceil(tiles / 256.0);
           const double balance = tiles / (per_cu * 256.0);
           // halo overhead (staging) and register-occupancy preference
-          const int pad = a.ntaps == 27 ? 1 : 0;
-          const double hv = (double)bs * ((bz - 1) * a.stride + 1 + 2 * pad) * ((by - 1) * a.stride + 1 + 2 * pad) *
-                            ((bx - 1) * a.stride + 1 + 2 * pad);
+          const double hv = (double)bs * ((bz - 1) * a.stride + a.td) * ((by - 1) * a.stride + a.td) *
+                            ((bx - 1) * a.stride + a.td);
           const double halo = 1.0 / (1.0 + 0.02 * hv / (32.0 * MB));
           const double occ = (MB * NB <= 4) ? 1.0 : 0.93;
           const double amort = 1.0 - 0.06 / (MB * NB);  // larger blocks amortise loads/epilogue
@@ -399,7 +447,8 @@ void pick_tile2(Op &op, int B) {
   const size_t lds = cm::conv2_lds_bytes(a, bMB, NB);
   const int occ = std::max(1, std::min((int)(160 * 1024 / lds), 2));
   const long tiles = (long)a.ntz * a.nty * a.ntx * B;
-  op.grid_x = (int)std::min<long>(tiles, 256L * occ);
+  (void)tiles;
+  op.grid_x = 256 * occ;
   op.tuned_B = B;
 }
 
@@ -415,6 +464,7 @@ struct ConvSpec {
   Act *out = nullptr;
   int Co = 0;
   int ci_valid = -1;  // valid input channels of the reference weight (first conv: 3 of 8)
+  bool stats = false; // produce the GroupNorm statistics of `out` in the epilogue
 };
 
 int add_conv(cm_model *m, const ConvSpec &s) {
@@ -428,6 +478,9 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   a.Zs = s.s0->Z; a.Ys = s.s0->Y; a.Xs = s.s0->X;
   a.Zo = s.out->Z; a.Yo = s.out->Y; a.Xo = s.out->X;
   a.ntaps = s.ntaps; a.stride = s.stride; a.ups = s.ups;
+  a.td = s.ntaps == 27 ? 3 : 1; a.par = 0; a.wpar_stride = 0;
+  const bool parity = s.ups && s.ntaps == 27 && !getenv("CM_NO_PARITY_UPCONV");
+  if (parity) { a.ups = 0; a.par = 1; a.td = 2; a.ntaps = 8; }
   a.out = s.out->d; a.out_cs = s.out->C; a.Co = s.Co;
   a.temb = s.temb; a.temb_stride = m->nproj; a.tidx = m->tbuf;
   a.resid = s.resid ? s.resid->d : nullptr; a.res_cs = s.resid ? s.resid->C : 0;
@@ -436,7 +489,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   a.nch0 = a.C0 / a.CK; a.nch1 = a.C1 / a.CK;
   // large-spatial 3x3x3 layers run on the persistent M-split kernel (all output
   // channels per workgroup, up to 128); the K-split kernel keeps the rest
-  op.v2 = (s.ntaps == 27 && a.CK == 32 && s.stride == 1 && s.out->V() >= 128 && !getenv("CM_NO_CONV2"));
+  op.v2 = (s.ntaps == 27 && !parity && a.CK == 32 && s.stride == 1 && s.out->V() >= 128 && getenv("CM_CONV2"));  // experimental
   op.NB = s.Co > 32 ? 2 : 1;
   if (op.v2) {
     if (dev_alloc(m, (void **)&op.d_ctr, 64 * sizeof(int))) return 1;
@@ -448,7 +501,19 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   const int Ci_pad = a.C0 + a.C1;
   if (Ci_ref > Ci_pad || (s.ci_valid < 0 && Ci_ref != Ci_pad))
     return fail("conv %s: weight has %d input channels, sources provide %d", s.wname.c_str(), Ci_ref, Ci_pad);
-  std::vector<float> wf = pack_conv_weights(w.host.data(), (int)w.shape[0], Ci_ref, s.ntaps, Ci_pad, a.CK, op.NB);
+  const std::vector<float> wi = to_internal_taps(w.host.data(), (int)w.shape[0], Ci_ref, s.ntaps);
+  std::vector<float> wf;
+  if (parity) {
+    const std::vector<float> wp = parity_weights(wi, (int)w.shape[0], Ci_ref);
+    const size_t per = (size_t)w.shape[0] * Ci_ref * 8;
+    for (int p8 = 0; p8 < 8; ++p8) {
+      std::vector<float> one = pack_conv_weights(wp.data() + p8 * per, (int)w.shape[0], Ci_ref, 8, Ci_pad, a.CK, op.NB);
+      a.wpar_stride = (long long)one.size();
+      wf.insert(wf.end(), one.begin(), one.end());
+    }
+  } else {
+    wf = pack_conv_weights(wi.data(), (int)w.shape[0], Ci_ref, s.ntaps, Ci_pad, a.CK, op.NB);
+  }
   float *dw = nullptr, *db = nullptr;
   if (upload(m, wf, &dw)) return 1;
   const int TN = 32 * op.NB, co_pad = (s.Co + TN - 1) / TN * TN;
@@ -456,6 +521,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   std::copy(b.host.begin(), b.host.end(), bp.begin());
   if (upload(m, bp, &db)) return 1;
   a.wfrag = dw; a.bias = db;
+  if (s.stats && !getenv("CM_NO_FUSED_STATS")) op.stat_act = s.out;
   op.flops_per_sample = 2.0 * s.out->V() * s.Co * (double)Ci_ref * s.ntaps;
   op.label = s.wname;
   m->ops.push_back(op);
@@ -463,6 +529,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
 }
 
 void add_stats(cm_model *m, const Act *a) {
+  if (!getenv("CM_NO_FUSED_STATS")) return;  // the producing conv writes the statistics in its epilogue
   Op op;
   op.kind = OP_STATS; op.cls = K_NORM; op.act = a; op.label = "stats(" + a->name + ")";
   m->ops.push_back(op);
@@ -526,7 +593,7 @@ int build_ops(cm_model *m) {
     Act *h1 = new_act(m, p + ".conv_1", b.cout, Zl[l], Yl[l], Xl[l], true, &rc);
     if (rc) return 1;
     ConvSpec c1; c1.s0 = x0; c1.s1 = x1; c1.gn = gn1; c1.silu = 1; c1.wname = p + ".conv_1.weight"; c1.bname = p + ".conv_1.bias";
-    c1.temb = m->temb_table + temb_off[p]; c1.out = h1; c1.Co = b.cout;
+    c1.temb = m->temb_table + temb_off[p]; c1.out = h1; c1.Co = b.cout; c1.stats = true;
     if (add_conv(m, c1)) return 1;
     add_stats(m, h1);
     if (add_gnfin(m, h1, nullptr, p + ".normalize_2.weight", p + ".normalize_2.bias", &gn2)) return 1;
@@ -544,7 +611,7 @@ int build_ops(cm_model *m) {
     Act *h2 = new_act(m, b.attention ? p + ".conv_2+skip" : p, b.cout, Zl[l], Yl[l], Xl[l], true, &rc);
     if (rc) return 1;
     ConvSpec c2; c2.s0 = h1; c2.gn = gn2; c2.silu = 1; c2.wname = p + ".conv_2.weight"; c2.bname = p + ".conv_2.bias";
-    c2.resid = resid; c2.out = h2; c2.Co = b.cout;
+    c2.resid = resid; c2.out = h2; c2.Co = b.cout; c2.stats = true;
     if (add_conv(m, c2)) return 1;
     add_stats(m, h2);
     *result = h2;
@@ -566,7 +633,7 @@ int build_ops(cm_model *m) {
       Act *h3 = new_act(m, p, b.cout, Zl[l], Yl[l], Xl[l], true, &rc);
       if (rc) return 1;
       ConvSpec co; co.s0 = ao; co.ntaps = 1; co.wname = ap + ".mhsa.out_proj.weight"; co.bname = ap + ".mhsa.out_proj.bias";
-      co.resid = h2; co.out = h3; co.Co = b.cout;
+      co.resid = h2; co.out = h3; co.Co = b.cout; co.stats = true;
       if (add_conv(m, co)) return 1;
       add_stats(m, h3);
       *result = h3;
@@ -578,7 +645,7 @@ int build_ops(cm_model *m) {
   Act *h = new_act(m, "first", c.base_channels, Zl[0], Yl[0], Xl[0], true, &rc);
   if (rc) return 1;
   {
-    ConvSpec cf; cf.s0 = m->x8_act; cf.wname = "first.weight"; cf.bname = "first.bias"; cf.out = h; cf.Co = c.base_channels; cf.ci_valid = c.in_channels;
+    ConvSpec cf; cf.s0 = m->x8_act; cf.wname = "first.weight"; cf.bname = "first.bias"; cf.out = h; cf.Co = c.base_channels; cf.ci_valid = c.in_channels; cf.stats = true;
     if (add_conv(m, cf)) return 1;
     add_stats(m, h);
   }
@@ -591,7 +658,7 @@ int build_ops(cm_model *m) {
     } else {
       Act *d = new_act(m, b.prefix, b.cout, Zl[b.level + 1], Yl[b.level + 1], Xl[b.level + 1], true, &rc);
       if (rc) return 1;
-      ConvSpec cd; cd.s0 = h; cd.stride = 2; cd.wname = b.prefix + ".downsample.weight"; cd.bname = b.prefix + ".downsample.bias"; cd.out = d; cd.Co = b.cout;
+      ConvSpec cd; cd.s0 = h; cd.stride = 2; cd.wname = b.prefix + ".downsample.weight"; cd.bname = b.prefix + ".downsample.bias"; cd.out = d; cd.Co = b.cout; cd.stats = true;
       if (add_conv(m, cd)) return 1;
       add_stats(m, d);
       h = d;
@@ -614,7 +681,7 @@ int build_ops(cm_model *m) {
       const int l = b.level - 1;
       Act *u = new_act(m, b.prefix, b.cout, Zl[l], Yl[l], Xl[l], true, &rc);
       if (rc) return 1;
-      ConvSpec cu; cu.s0 = h; cu.ups = 1; cu.wname = b.prefix + ".upsample.1.weight"; cu.bname = b.prefix + ".upsample.1.bias"; cu.out = u; cu.Co = b.cout;
+      ConvSpec cu; cu.s0 = h; cu.ups = 1; cu.wname = b.prefix + ".upsample.1.weight"; cu.bname = b.prefix + ".upsample.1.bias"; cu.out = u; cu.Co = b.cout; cu.stats = true;
       if (add_conv(m, cu)) return 1;
       add_stats(m, u);
       h = u;
@@ -682,9 +749,10 @@ int run_ops(cm_model *m, int B, hipStream_t st) {
     }
     switch (op.kind) {
       case OP_CONV: {
-        if (op.tuned_B != B) {
-          if (op.v2) pick_tile2(op, B);
-          else pick_tile(op, B);
+        if (op.tuned_B < 0) {
+          if (op.v2) pick_tile2(op, TUNE_BATCH);
+          else pick_tile(op, TUNE_BATCH);
+          op.tuned_B = B;
           std::vector<int> hv((size_t)cm::conv_halo_voxels(op.ca)), mt((size_t)32 * op.MB);
           cm::conv_build_tables(op.ca, op.MB, hv.data(), mt.data());
           if (!op.d_hvtab) {
@@ -700,18 +768,32 @@ int run_ops(cm_model *m, int B, hipStream_t st) {
         }
         op.ca.B = B;
         op.ca.nts = (B + op.ca.bs - 1) / op.ca.bs;
-        if (op.v2) CM_HIP(cm::launch_conv2(op.ca, op.MB, op.NB, op.grid_x, op.d_ctr, st));
+        if (op.stat_act) {
+          const int ns = op.ca.ntz * op.ca.nty * op.ca.ntx * op.MB * (op.ca.par ? 8 : 1);
+          if (ns > MAX_SLOTS) return fail("statistics slots %d exceed %d", ns, MAX_SLOTS);
+          op.ca.stat_part = op.stat_act->part;
+          op.ca.stat_cnt = op.stat_act->cnt;
+          op.ca.stat_C = op.stat_act->C;
+          op.ca.stat_ns = ns;
+          op.stat_act->nslots = ns;
+        }
+        if (op.v2) {
+          const long tiles = (long)op.ca.ntz * op.ca.nty * op.ca.ntx * B;
+          const int gx = (int)std::min<long>(tiles, op.grid_x);
+          CM_HIP(cm::launch_conv2(op.ca, op.MB, op.NB, gx, op.d_ctr, st));
+        }
         else CM_HIP(cm::launch_conv(op.ca, op.MB, op.NB, st));
         break;
       }
       case OP_STATS:
-        CM_HIP(cm::launch_chan_stats(op.act->d, B, op.act->V(), op.act->C, op.act->nslice, op.act->part, st));
+        CM_HIP(cm::launch_chan_stats(op.act->d, B, op.act->V(), op.act->C, op.act->nslice, op.act->part, op.act->cnt, st));
+        const_cast<Act *>(op.act)->nslots = op.act->nslice;
         break;
       case OP_GNFIN:
-        if (op.g1 && (op.g1->nslice != op.g0->nslice || op.g1->V() != op.g0->V()))
-          return fail("concat sources disagree on statistics slicing");
-        CM_HIP(cm::launch_gn_finalize(op.g0->part, op.g0->C, op.g1 ? op.g1->part : nullptr, op.g1 ? op.g1->C : 0,
-                                      op.g0->nslice, op.g0->V(), op.gamma, op.beta, GN_GROUPS, GN_EPS, op.gn_out, B, st));
+        if (op.g1 && op.g1->V() != op.g0->V()) return fail("concat sources disagree on voxel count");
+        CM_HIP(cm::launch_gn_finalize(op.g0->part, op.g0->cnt, op.g0->nslots, op.g0->C, op.g1 ? op.g1->part : nullptr,
+                                      op.g1 ? op.g1->cnt : nullptr, op.g1 ? op.g1->nslots : 0, op.g1 ? op.g1->C : 0,
+                                      op.g0->V(), op.gamma, op.beta, GN_GROUPS, GN_EPS, op.gn_out, B, st));
         break;
       case OP_ATTN:
         CM_HIP(cm::launch_attn_core(op.qkv, op.aout, B, op.S, op.E, ATTN_HEADS, st));
