@@ -154,14 +154,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     __syncthreads();  // tables ready (first pass) / previous chunk fully consumed
     // ---- stage the halo tile of this channel chunk ---------------------------
     // (loads are issued in batches of SU so that their latencies overlap)
-    constexpr int SU = 4;
+    constexpr int SU = 6;   // loads in flight per thread per batch (their latencies overlap)
     const float *srcq = src + c0 + 4 * q4;
     // Branch-free: loads inside divergent branches make hipcc fall back to vmcnt(0) waits.
     // Out-of-range halo voxels read voxel 0 (a cached line) and are zeroed before the
     // LDS write; the hvtab entries beyond HV are clamped to the last valid one.
+    // GroupNorm scale / shift of this thread's channel quad: one pair per chunk when the tile
+    // holds a single sample (the common case), looked up per voxel otherwise
+    f32x4 sc1 = {1.f, 1.f, 1.f, 1.f}, sh1 = {0.f, 0.f, 0.f, 0.f};
+    if (a.gn && a.bs == 1) {
+      const float *g = a.gn + (size_t)(b0 < a.B ? b0 : 0) * 2 * Ctot + cg0 + 4 * q4;
+      sc1 = *reinterpret_cast<const f32x4 *>(g);
+      sh1 = *reinterpret_cast<const f32x4 *>(g + Ctot);
+    }
     for (int hv0 = v0; hv0 < HV && !(a.dbg & 1); hv0 += vstep * SU) {
       int pk[SU];
-      f32x4 v[SU], sc[SU], sh[SU];
+      f32x4 v[SU];
+      int bbv[SU];
       bool ok[SU];
 #pragma unroll
       for (int u = 0; u < SU; ++u) {
@@ -175,20 +184,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int b = b0 + (pk[u] >> 26);
         ok[u] = hv < HV && b < a.B && cz >= 0 && cz < Zc && cy >= 0 && cy < Yc && cx >= 0 && cx < Xc;
         const int off = ok[u] ? ((b * a.Zs + (cz >> a.ups)) * a.Ys + (cy >> a.ups)) * a.Xs + (cx >> a.ups) : 0;
-        const int bb = b < a.B ? b : 0;
+        bbv[u] = b < a.B ? b : 0;
         v[u] = *reinterpret_cast<const f32x4 *>(srcq + (size_t)off * Cs);
-        if (a.gn) {
-          const float *g = a.gn + (size_t)bb * 2 * Ctot + cg0 + 4 * q4;
-          sc[u] = *reinterpret_cast<const f32x4 *>(g);
-          sh[u] = *reinterpret_cast<const f32x4 *>(g + Ctot);
-        }
       }
 #pragma unroll
       for (int u = 0; u < SU; ++u) {
         const int hv = hv0 + u * vstep;
         f32x4 w = v[u];
-        if (a.gn) {
-          w = w * sc[u] + sh[u];
+        if (a.gn && !(a.dbg & 128)) {
+          f32x4 sc = sc1, sh = sh1;
+          if (a.bs != 1) {
+            const float *g = a.gn + (size_t)bbv[u] * 2 * Ctot + cg0 + 4 * q4;
+            sc = *reinterpret_cast<const f32x4 *>(g);
+            sh = *reinterpret_cast<const f32x4 *>(g + Ctot);
+          }
+          w = w * sc + sh;
           if (a.silu) { w[0] = silu_f(w[0]); w[1] = silu_f(w[1]); w[2] = silu_f(w[2]); w[3] = silu_f(w[3]); }
         }
         if (!ok[u]) w = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -204,18 +214,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       // the MFMAs in a register ring (static indices: 27 = 9 x PD) and the stream
       // continues across chunk boundaries, so neither the L2 latency nor the staging
       // barrier exposes a weight load.
+      // A fragments are read one tap ahead of their MFMAs (register double buffer), so the
+      // LDS latency (bank conflicts included) hides behind 4*MB*NB MFMAs as well.
+      auto tap_off = [&](int t) {
+        int dz, dy, dx;
+        if constexpr (TAPS == 27) { dz = t / 9; const int rem = t - dz * 9; dy = rem / 3; dx = rem - dy * 3; }
+        else { dz = t >> 2; dy = (t >> 1) & 1; dx = t & 1; }
+        return ((dz * HY + dy) * HX + dx) * S + wave * 8;
+      };
+      f32x4 afn[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) afn[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + tap_off(0)]);
 #pragma unroll 1
       for (int i0 = 0; i0 < TAPS; i0 += PD) {
 #pragma unroll
         for (int d = 0; d < PD; ++d) {
           const int t = i0 + d;  // tap index
-          int dz, dy, dx;
-          if constexpr (TAPS == 27) { dz = t / 9; const int rem = t - dz * 9; dy = rem / 3; dx = rem - dy * 3; }
-          else { dz = t >> 2; dy = (t >> 1) & 1; dx = t & 1; }
-          const int aoff = ((dz * HY + dy) * HX + dx) * S + wave * 8;
           f32x4 af[MB];
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) af[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + aoff]);
+          for (int mb = 0; mb < MB; ++mb) af[mb] = afn[mb];
+          const int aoffn = tap_off(t + 1 < TAPS ? t + 1 : t);  // (the last tap re-reads itself)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) afn[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + aoffn]);
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
           int tn = t + PD, chn = ch;
           if (tn >= TAPS) { tn -= TAPS; chn += 1; }
           if (chn < nchunks) {
-            const f32x4 *wp = wtile + ((size_t)chn * (TAPS * 4) + (wave + 4 * tn)) * NB * 64;
+            const f32x4 *wp = (a.dbg & 64) ? wtile : wtile + ((size_t)chn * (TAPS * 4) + (wave + 4 * tn)) * NB * 64;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) bq[d][nb] = wp[nb * 64];
           }
@@ -342,7 +362,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg)
             if (nok && offs[reg] >= 0) a.out[(size_t)offs[reg] * a.out_cs + n] = rs[reg];
-          if (a.stat_part) {
+          if (a.stat_part && !(a.dbg & 256)) {
             // fused GroupNorm statistics of this 32-row block (two-pass on registers, the
             // two lane halves merged with one cross-lane exchange): layers.py:30,41 read them
             float s1 = 0.f, cnt = 0.f;

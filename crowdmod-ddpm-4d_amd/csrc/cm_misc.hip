@@ -305,6 +305,11 @@ hipError_t launch_time_mlp(const float *table, const float *W1, const float *b1,
 template <int D>
 __global__ __launch_bounds__(256) void attn_core_kernel(const float *__restrict__ qkv, float *__restrict__ out, int S,
                                                         int E) {
+  // PARTS adjacent lanes share one query row, each owning 8 of the D head dims: the
+  // q.k dot product is finished with PARTS-wide xor-shuffles, the softmax state is
+  // replicated, and every lane accumulates its 8 output dims.
+  constexpr int PARTS = D / 8;
+  constexpr int ROWS = 256 / PARTS;
   extern __shared__ float sm[];  // K[S][D], V[S][D]
   float *Ks = sm, *Vs = sm + (size_t)S * D;
   const int hd = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -318,32 +323,43 @@ __global__ __launch_bounds__(256) void attn_core_kernel(const float *__restrict_
   }
   __syncthreads();
   const float scale = rsqrtf((float)D);
-  for (int row = tid; row < S; row += 256) {
-    float q[D], o[D];
-    const float *qp = base + (size_t)row * 3 * E + hd * D;
-#pragma unroll
-    for (int d = 0; d < D; ++d) { q[d] = qp[d] * scale; o[d] = 0.f; }
+  const int part = tid % PARTS, rl = tid / PARTS;
+  for (int row0 = 0; row0 < S; row0 += ROWS) {
+    const int row = row0 + rl;
+    const int rowc = row < S ? row : S - 1;  // surplus lanes shadow the last row (shuffles stay convergent)
+    const float *qp = base + (size_t)rowc * 3 * E + hd * D + 8 * part;
+    const f32x4 q0 = *reinterpret_cast<const f32x4 *>(qp) * scale;
+    const f32x4 q1 = *reinterpret_cast<const f32x4 *>(qp + 4) * scale;
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
     float mx = -3.0e38f, l = 0.f;
     for (int j = 0; j < S; ++j) {
-      float sc = 0.f;
+      const f32x4 k0 = *reinterpret_cast<const f32x4 *>(Ks + j * D + 8 * part);
+      const f32x4 k1 = *reinterpret_cast<const f32x4 *>(Ks + j * D + 8 * part + 4);
+      float sc = q0[0] * k0[0];
+      sc = fmaf(q0[1], k0[1], sc); sc = fmaf(q0[2], k0[2], sc); sc = fmaf(q0[3], k0[3], sc);
+      sc = fmaf(q1[0], k1[0], sc); sc = fmaf(q1[1], k1[1], sc); sc = fmaf(q1[2], k1[2], sc); sc = fmaf(q1[3], k1[3], sc);
 #pragma unroll
-      for (int d = 0; d < D; ++d) sc = fmaf(q[d], Ks[j * D + d], sc);
+      for (int m = 1; m < PARTS; m <<= 1) sc += __shfl_xor(sc, m);
+      const f32x4 v0 = *reinterpret_cast<const f32x4 *>(Vs + j * D + 8 * part);
+      const f32x4 v1 = *reinterpret_cast<const f32x4 *>(Vs + j * D + 8 * part + 4);
       if (sc > mx) {
         const float corr = __expf(mx - sc);
         l *= corr;
-#pragma unroll
-        for (int d = 0; d < D; ++d) o[d] *= corr;
+        o0 *= corr;
+        o1 *= corr;
         mx = sc;
       }
       const float p = __expf(sc - mx);
       l += p;
-#pragma unroll
-      for (int d = 0; d < D; ++d) o[d] = fmaf(p, Vs[j * D + d], o[d]);
+      o0 += v0 * p;
+      o1 += v1 * p;
     }
-    const float inv = 1.0f / l;
-    float *op = out + ((size_t)b * S + row) * E + hd * D;
-#pragma unroll
-    for (int d = 0; d < D; ++d) op[d] = o[d] * inv;
+    if (row < S) {
+      const float inv = 1.0f / l;
+      float *op = out + ((size_t)b * S + row) * E + hd * D + 8 * part;
+      *reinterpret_cast<f32x4 *>(op) = o0 * inv;
+      *reinterpret_cast<f32x4 *>(op + 4) = o1 * inv;
+    }
   }
 }
 

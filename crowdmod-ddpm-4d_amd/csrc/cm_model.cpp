@@ -485,6 +485,13 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   a.temb = s.temb; a.temb_stride = m->nproj; a.tidx = m->tbuf;
   a.resid = s.resid ? s.resid->d : nullptr; a.res_cs = s.resid ? s.resid->C : 0;
   a.CK = pick_ck(a.C0, a.C1);
+  if (s.ntaps == 1) {
+    // 1x1x1 convs have no halo: stage as many channels per pass as the sources allow
+    // (a chunk may not straddle the concat boundary), so a whole K = Ci contraction needs
+    // one or two staging rounds instead of Ci/32.
+    for (int ck : {256, 128, 64})
+      if (a.C0 % ck == 0 && a.C1 % ck == 0) { a.CK = ck; break; }
+  }
   if (!a.CK) return fail("conv %s: channel counts %d/%d not multiples of 8", s.wname.c_str(), a.C0, a.C1);
   a.nch0 = a.C0 / a.CK; a.nch1 = a.C1 / a.CK;
   // large-spatial 3x3x3 layers run on the persistent M-split kernel (all output
