@@ -42,6 +42,17 @@ def load_cfg(channels: int):
     return cfg, cfgmod.resolve(cfg, "DDPM-UNet")
 
 
+def hbm_traffic():
+    """HBM bytes per launch of the dominant kernel class, from the rocprofv3 PMC passes of
+    tools/profile_round.sh (FETCH_SIZE x2-corrected + WRITE_SIZE; see profiles/hbm_traffic.json).
+    bench.py cannot collect PMC counters on itself, so the committed measurement is quoted."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fo:
+        return json.load(fo).get("hbm_bytes_per_launch")
+
+
 def cpu_baseline(res, channels: int, batch: int, budget_s: float):
     """Time the CPU port (oracle/unet_torch.py) on a bounded sample of the same workload."""
     import torch
@@ -162,9 +173,9 @@ def main():
         conv_s = ms[0] / 1e3
         ach = conv3_flops / conv_s / 1e12 if conv_s > 0 else 0.0
         roofline = {
-            "kernel": "conv_mfma_kernel (3x3x3 implicit-GEMM, v_mfma_f32_32x32x2_f32)",
+            "kernel": "conv_mfma_kernel<*,*,27|8|0> -- all 3x3x3 conv launches (implicit GEMM, v_mfma_f32_32x32x2_f32)",
             "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": hbm_traffic(),
             "launches": int(cnt[0]), "avg_launch_us": ms[0] * 1e3 / max(1, cnt[0]),
             "algorithmic_gflop_per_launch": conv3_flops / max(1, cnt[0]) / 1e9,
             "class_ms_per_step": {k: ms[i] / a.steps for i, k in enumerate(

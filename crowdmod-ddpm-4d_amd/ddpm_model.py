@@ -149,3 +149,44 @@ class DDPM_model:
             return x, hist
         # without history the device-drawn x_T is not copied back (None stands in for it)
         return x, [x_T, x]
+
+    # ------------------------------------------------------------------------------
+    def load_checkpoint(self, model_fullname: str):
+        """ddpm.py:288: load_state_dict(torch.load(path, map_location='cpu', weights_only=True)['model'])."""
+        from . import checkpoint
+        self.denoiser.load_state_dict(checkpoint.load_model_state(model_fullname))
+        return self
+
+    def sampling(self, batched_test_data, plotType=None, model_fullname=None, plotMprop=None, plotPast=None,
+                 samePastSeq=False, macropropPlotter=None, *, rng: Optional[np.random.Generator] = None):
+        """ddpm.py:284-334 without the matplotlib tail: load the checkpoint, take the first
+        batch, draw NSAMPLES4PLOTS past windows (all equal if `samePastSeq`), run the
+        configured sampler and return (predictions, past_idx, pasts, futures).  Plotting
+        is the caller's business (`macropropPlotter` is accepted for signature parity)."""
+        import logging
+        r = self.res
+        if model_fullname is not None:
+            self.load_checkpoint(model_fullname)
+        sampler = DDPM(timesteps=r.timesteps, scale=r.scale, device=self.device)
+        rng = rng or np.random.default_rng(42)
+        for past_test, future_test in batched_test_data:
+            past_test = np.asarray(past_test, dtype=np.float32)
+            future_test = np.asarray(future_test, dtype=np.float32)
+            nsamples = past_test.shape[0] if self.from_fixed_past else min(r.nsamples4plots, past_test.shape[0])
+            if self.from_fixed_past:
+                idx = np.arange(nsamples)
+            else:
+                idx = rng.permutation(past_test.shape[0])[:nsamples]
+                if samePastSeq:
+                    idx[:] = idx[0]
+            pasts, futures = past_test[idx], future_test[idx]
+            if r.sampler == "DDPM":
+                pred, _ = self._generate_ddpm(pasts, sampler, nsamples)
+                logging.info("L1 norm %.2f", float(np.mean(np.abs(pred[:, 0]))))
+            elif r.sampler == "DDIM":
+                taus = np.arange(0, r.timesteps - 1, r.ddim_divider)
+                pred, _ = self._generate_ddim(pasts, taus, sampler, nsamples)
+            else:
+                raise ValueError(f"{r.sampler} sampler not supported")
+            return pred, idx, pasts, futures   # the reference breaks after the first batch (ddpm.py:334)
+        raise ValueError("empty test data")

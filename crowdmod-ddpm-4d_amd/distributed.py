@@ -1,0 +1,52 @@
+"""Multi-GPU sampling: batch-shard the independent chains, one process per GPU.
+
+The reference has no distributed code.  Sampling chains are
+independent -- GroupNorm and attention are per sample (layers.py:15-16,30) -- so the
+only collective is one gather of the finished samples: `torch.distributed` all_gather
+(backend "nccl" == RCCL over xGMI on the MI355X node, "gloo" in the CPU tests).  Each
+chain's noise is addressed by its GLOBAL sample index, so the gathered result is
+bit-identical to the single-process run whatever the world size.
+"""
+from __future__ import annotations
+
+from typing import Callable, Tuple
+
+import numpy as np
+
+
+def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of the global batch owned by `rank` (blocks differ by <= 1)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_samples(local, global_batch: int, rank: int, world: int, group=None):
+    """All-gather the per-rank blocks (possibly of unequal length) into the full batch.
+
+    `local` is a torch tensor (CUDA with nccl, CPU with gloo) or a numpy array (CPU)."""
+    import torch
+    import torch.distributed as dist
+    is_np = isinstance(local, np.ndarray)
+    t = torch.from_numpy(np.ascontiguousarray(local)) if is_np else local.contiguous()
+    if world == 1:
+        return local
+    sizes = [shard_range(global_batch, r, world) for r in range(world)]
+    maxn = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((maxn,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    out = torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+    return out.cpu().numpy() if is_np else out
+
+
+def sample_sharded(generate: Callable, past_global, global_batch: int, rank: int, world: int, group=None):
+    """Run `generate(past_shard, nsamples, sample_id_base)` on this rank's block and gather.
+
+    `generate` is e.g. `lambda p, n, base: model._generate_ddpm(p, sampler, n, sample_id_base=base)[0]`."""
+    lo, hi = shard_range(global_batch, rank, world)
+    local = generate(past_global[lo:hi], hi - lo, lo)
+    return gather_samples(local, global_batch, rank, world, group)

@@ -1,0 +1,253 @@
+"""CPU-only tests of the host logic: C-ABI surface, config schemas, checkpoint interop,
+schedule tables, multi-process sharding (gloo, world_size 2).  No GPU compute calls."""
+import ctypes as C
+import os
+import re
+import socket
+import sys
+import tempfile
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from crowdmod_ddpm_4d_amd import checkpoint, config as cfgmod, distributed, native, prng, spec
+from helpers import load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_symbol_of_the_header():
+    hdr = open(os.path.join(ROOT, "include", "crowdmod_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(cm_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 30
+    lib = native.lib()
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert names == set(native.SIGNATURES), names ^ set(native.SIGNATURES)
+    assert lib.cm_abi_version() == 1
+
+
+def test_error_reporting_without_gpu_is_loud():
+    lib = native.lib()
+    c = native.cm_unet_config()
+    c.in_channels = c.out_channels = 3
+    c.num_res_blocks, c.base_channels, c.n_levels = 1, 12, 1  # 12 is not a multiple of 8
+    c.channel_mult[0] = 1
+    c.time_multiple, c.rows, c.cols, c.past_len, c.future_len, c.max_batch, c.device = 4, 4, 8, 5, 3, 1, 0
+    h = C.c_void_p()
+    assert lib.cm_model_create(C.byref(c), C.byref(h)) != 0
+    assert b"multiple of 8" in lib.cm_last_error()
+    with pytest.raises(native.NativeError):
+        native.check(lib.cm_model_create(C.byref(c), C.byref(h)))
+
+
+def test_schedule_tables_host_only_match_reference():
+    """cm_schedule_create with device < 0 is pure host code: ForwardSampler.__init__ tables."""
+    lib = native.lib()
+    g = load("schedule.npz")
+    for T, scale in ((1000, 0.5), (50, 0.5), (1000, 1.0)):
+        h = C.c_void_p()
+        native.check(lib.cm_schedule_create(T, scale, 1e-4, 2e-2, -1, C.byref(h)))
+        for i, name in enumerate(native.TABLES):
+            buf = np.empty(T, dtype=np.float32)
+            native.check(lib.cm_schedule_table(h, i, buf.ctypes.data, T))
+            ref = g[f"T{T}_s{scale}/{name}"]
+            if name in ("beta", "alpha", "alpha_bar"):
+                assert np.array_equal(buf, ref), (T, scale, name)
+            else:
+                np.testing.assert_allclose(buf, ref, rtol=1.2e-7)
+        o = native.cm_sample_opts()
+        o.sampler, o.ddim_divider = native.SAMPLER_DDIM, 100
+        n = C.c_int32()
+        native.check(lib.cm_sample_num_steps(h, C.byref(o), C.byref(n)))
+        assert n.value == len(np.arange(0, T - 1, 100))
+        o.sampler = native.SAMPLER_DDPM
+        native.check(lib.cm_sample_num_steps(h, C.byref(o), C.byref(n)))
+        assert n.value == T
+        native.check(lib.cm_schedule_destroy(h))
+
+
+SCHEMA_CURRENT = """
+MACROPROPS: {ROWS: 12, COLS: 36}
+DATASET: {PAST_LEN: 5, FUTURE_LEN: 3, BATCH_SIZE: 64}
+MODEL:
+  NSAMPLES: 1280
+  NSAMPLES4PLOTS: 20
+  DDPM:
+    SAMPLER: "DDIM"
+    TIMESTEPS: 1000
+    SCALE: 0.5
+    SIGMA: 0.001
+    DDIM_DIVIDER: 2
+    GUIDANCE: 'Sparsity'
+    LAMBDA_GUIDANCE: 0.004
+    UNET: {CONDITION: "Past", NUM_RES_BLOCKS: 1, BASE_CH: 32, BASE_CH_MULT: [1, 2, 4],
+           APPLY_ATTENTION: [False, False, True, False], DROPOUT_RATE: 0.1, TIME_EMB_MULT: 4,
+           TRAIN: {EPOCHS: 200, SOLVER: {LR: 0.00005}}}
+"""
+SCHEMA_4TEST = """
+MACROPROPS: {ROWS: 12, COLS: 36}
+DATASET: {PAST_LEN: 5, FUTURE_LEN: 3, BATCH_SIZE: 8}
+MODEL:
+  CONDITION: "Past"
+  NUM_RES_BLOCKS: 1
+  BASE_CH: 32
+  BASE_CH_MULT: [1, 2, 4]
+  APPLY_ATTENTION: [False, False, True, False]
+  DROPOUT_RATE: 0.1
+  TIME_EMB_MULT: 4
+  DDPM: {SAMPLER: "DDPM", TIMESTEPS: 200, SCALE: 0.5, GUIDANCE: 'sparsity', TRAIN: {EPOCHS: 3}}
+"""
+SCHEMA_FLAT = """
+MACROPROPS: {ROWS: 12, COLS: 36}
+DATASET: {PAST_LEN: 5, FUTURE_LEN: 3, BATCH_SIZE: 64}
+MODEL: {CONDITION: "Past", NUM_RES_BLOCKS: 2, BASE_CH: 16, BASE_CH_MULT: [1, 2], APPLY_ATTENTION: [False, True],
+        DROPOUT_RATE: 0.05, TIME_EMB_MULT: 4}
+DIFFUSION: {SAMPLER: "DDPM", TIMESTEPS: 1000, SCALE: 0.5, DDIM_DIVIDER: 90, NSAMPLES: 640, NSAMPLES4PLOTS: 10,
+            GUIDANCE: 'mass_preservation'}
+TRAIN: {EPOCHS: 250, SOLVER: {LR: 0.00005}}
+"""
+
+
+def _cfg(text):
+    with tempfile.NamedTemporaryFile("w", suffix=".yml", delete=False) as f:
+        f.write(text)
+    try:
+        return cfgmod.getYamlConfig(f.name)
+    finally:
+        os.unlink(f.name)
+
+
+def test_config_three_schema_generations():
+    r = cfgmod.resolve(_cfg(SCHEMA_CURRENT))
+    assert (r.rows, r.cols, r.timesteps, r.sampler, r.guidance, r.lambda_guidance) == (12, 36, 1000, "DDIM", "Sparsity", 0.004)
+    assert r.base_ch_mult == (1, 2, 4) and r.apply_attention == (False, False, True, False) and r.train.EPOCHS == 200
+    r = cfgmod.resolve(_cfg(SCHEMA_4TEST))
+    assert (r.timesteps, r.base_ch, r.batch_size, r.guidance) == (200, 32, 8, "sparsity") and r.train.EPOCHS == 3
+    r = cfgmod.resolve(_cfg(SCHEMA_FLAT))
+    assert (r.num_res_blocks, r.base_ch, r.base_ch_mult, r.nsamples, r.ddim_divider) == (2, 16, (1, 2), 640, 90)
+    assert r.train.EPOCHS == 250
+    shipped = cfgmod.resolve(cfgmod.getYamlConfig(os.path.join(ROOT, "config", "ATC.yml")))
+    assert (shipped.rows, shipped.cols, shipped.base_ch, shipped.timesteps) == (12, 36, 32, 1000)
+    hermes = cfgmod.resolve(cfgmod.getYamlConfig(os.path.join(ROOT, "config", "HERMES-CR-120.yml")))
+    assert (hermes.rows, hermes.cols) == (28, 24)
+
+
+def test_attr_dict_and_missing_file():
+    cfg = _cfg(SCHEMA_CURRENT)
+    assert cfg.MODEL.DDPM.UNET.BASE_CH == 32 and cfg["MODEL"]["DDPM"]["SCALE"] == 0.5
+    with pytest.raises(AttributeError):
+        _ = cfg.MODEL.DDPM.NOPE
+    with pytest.raises(FileNotFoundError):
+        cfgmod.getYamlConfig("/nonexistent.yml")
+
+
+def test_checkpoint_interop_both_directions(tmp_path):
+    cfg = spec.UNetConfig(3, 3, 1, 8, (1, 2, 4), (False, False, True, False))
+    P = spec.init_params(cfg, 1)
+    sd = OrderedDict((k, torch.from_numpy(v.copy())) for k, v in P.items())
+    a = str(tmp_path / "a.pth")
+    torch.save({"opt": {"state": {}, "param_groups": [{"lr": 5e-5, "betas": (0.5, 0.999)}]}, "model": sd}, a)
+    m = checkpoint.load_model_state(a)
+    assert list(m) == list(P) and all(np.array_equal(m[k], P[k]) for k in P)
+    t = torch.arange(24, dtype=torch.float32).reshape(4, 6).t()          # non-contiguous view
+    b = str(tmp_path / "b.pth")
+    torch.save({"model": {"x": t}}, b)
+    assert np.array_equal(checkpoint.load_model_state(b)["x"], t.numpy())
+    c = str(tmp_path / "c.pth")
+    checkpoint.save_checkpoint(P, c, opt_state={"state": {}, "param_groups": [{"lr": 5e-5, "betas": (0.5, 0.999)}]})
+    o = torch.load(c, map_location="cpu", weights_only=True)
+    assert list(o["model"]) == list(P) and all(np.array_equal(o["model"][k].numpy(), P[k]) for k in P)
+    assert o["opt"]["param_groups"][0]["betas"] == (0.5, 0.999)
+
+
+def test_checkpoint_rejects_code_execution(tmp_path):
+    import pickle
+    import zipfile
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+
+    p = str(tmp_path / "evil.pth")
+    with zipfile.ZipFile(p, "w") as zf:
+        zf.writestr("archive/data.pkl", pickle.dumps({"model": Evil()}, protocol=2))
+        zf.writestr("archive/version", "3\n")
+    with pytest.raises(pickle.UnpicklingError):
+        checkpoint.load(p)
+
+
+def test_unet_host_mirror_state_dict_contract():
+    from crowdmod_ddpm_4d_amd.unet import UNet
+    net = UNet(3, 3, 1, 8, (1, 2, 4), (False, False, True, False), 0.1, 4, "Past")
+    sd = net.state_dict()
+    assert list(sd) == list(spec.param_shapes(net.cfg)) and len(sd) == 169
+    with pytest.raises(RuntimeError, match="missing keys"):
+        net.load_state_dict({k: v for k, v in sd.items() if k != "first.bias"})
+    bad = dict(sd)
+    bad["first.bias"] = np.zeros(9, np.float32)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        net.load_state_dict(bad)
+    with pytest.raises(NotImplementedError):
+        UNet(3, 3, 1, 8, (1, 2, 4), (False, False, True, False), condition="None")
+
+
+def test_prng_is_order_and_shard_independent():
+    a = prng.normal_per_sample(7, "z/x", np.arange(8), 100, step=3)
+    b = prng.normal_per_sample(7, "z/x", np.arange(4, 8), 100, step=3)
+    assert np.array_equal(a[4:], b)
+    assert not np.array_equal(a[0], prng.normal_per_sample(7, "z/x", [0], 100, step=4)[0])
+    z = prng.normal(1, "moments", 200000)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
+
+
+def test_shard_ranges_partition_the_batch():
+    for gb in (1, 7, 64, 512, 1280):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = distributed.shard_range(gb, r, world)
+                cover += list(range(lo, hi))
+            assert cover == list(range(gb))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, gb, out_dir):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = 12
+    past = prng.normal(3, "past", gb * per).reshape(gb, per)
+
+    def generate(p, n, base):
+        # stands in for the on-device loop: depends on the chain's past and its GLOBAL index only
+        z = prng.normal_per_sample(9, "z", np.arange(base, base + n), per, step=0)
+        return (np.tanh(p) + 0.5 * z).astype(np.float32)
+
+    full = distributed.sample_sharded(generate, past, gb, rank, world)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gb", [8, 7])
+def test_gloo_two_ranks_sharded_sampling_equals_single_process(tmp_path, gb):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, gb, str(tmp_path)), nprocs=world, join=True)
+    per = 12
+    past = prng.normal(3, "past", gb * per).reshape(gb, per)
+    want = (np.tanh(past) + 0.5 * prng.normal_per_sample(9, "z", np.arange(gb), per, step=0)).astype(np.float32)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"r{r}.npy"))
+        assert np.array_equal(got, want), r
