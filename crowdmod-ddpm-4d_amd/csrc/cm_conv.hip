@@ -21,7 +21,10 @@
 //     wave applies bias + time-embedding + residual and stores channels-last.
 #include "cm_kernels.h"
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace cm {
 
@@ -33,7 +36,7 @@ __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_r
 
 // FAST = 0: generic step loop; 27 / 8: CK == 32 with that many taps (register weight ring)
 template <int MB, int NB, int FAST>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TM = 32 * MB;
   constexpr int TN = 32 * NB;
@@ -45,6 +48,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
 
+  // diagnostic build path (dbg bit 3): wall-clock stamps (100 MHz) of this workgroup's phases
+  unsigned long long tst[6] = {0, 0, 0, 0, 0, 0};
+#define CM_RT(i) if (a.dbg & 8) tst[i] = __builtin_amdgcn_s_memrealtime();
+  CM_RT(0)
   int tile = blockIdx.x;
   const int tx = tile % a.ntx; tile /= a.ntx;
   const int ty = tile % a.nty; tile /= a.nty;
@@ -130,23 +137,54 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int Ctot = a.C0 + a.C1;
   const f32x4 *wtile = reinterpret_cast<const f32x4 *>(a.wfrag + (size_t)par * a.wpar_stride) +
                        (size_t)nt * nchunks * nsteps * NB * 64 + lane;
+  // K split over workgroups (tiny-spatial layers): this one owns chunks [ch0, ch1)
+  const int kz = (a.ks > 1) ? (int)blockIdx.z : 0;
+  const int ch0 = (a.ks > 1) ? kz * nchunks / a.ks : 0;
+  const int ch1 = (a.ks > 1) ? (kz + 1) * nchunks / a.ks : nchunks;
+  float *const outp = a.out + (size_t)kz * a.kpart;
 
   const int q4 = tid % K4, v0 = tid / K4, vstep = 256 / K4;
 
   constexpr bool fast = FAST != 0;           // host guarantees CK == 32 && ntaps == FAST
   constexpr int TAPS = FAST ? FAST : 27;
-  constexpr int PD = (TAPS == 27) ? 3 : 2;   // weight prefetch depth of the fast path (taps), TAPS % PD == 0
+  constexpr int PD = (TAPS == 27) ? CM_PD27 : CM_PD8;   // weight prefetch depth of the fast path (taps), TAPS % PD == 0
   f32x4 bq[PD][NB];
   if constexpr (fast) {
 #pragma unroll
     for (int d = 0; d < PD; ++d) {
-      const f32x4 *wp = wtile + (size_t)(wave + 4 * d) * NB * 64;
+      const f32x4 *wp = wtile + ((size_t)ch0 * (TAPS * 4) + (wave + 4 * d)) * NB * 64;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) bq[d][nb] = wp[nb * 64];
     }
   }
 
-  for (int ch = 0; ch < nchunks; ++ch) {
+  // Fast staging (32-channel chunks, one sample per tile): this thread's halo voxels and
+  // their source offsets are resolved ONCE per workgroup; every chunk then issues all its
+  // loads back to back (one memory latency per chunk instead of one per dependent step --
+  // a global load costs 1.5-2 us under load on this part, profiles/round1_notes.md).
+  constexpr int NVM = 12;                        // halo float4 per thread (HV <= 384)
+  const bool fstage = fast && a.bs == 1 && HV <= NVM * 32;
+  int soff[NVM];
+  unsigned okmask = 0;
+  if (fstage) {
+    int pkk[NVM];
+#pragma unroll
+    for (int k = 0; k < NVM; ++k) {
+      const int hv = v0 + k * 32;
+      pkk[k] = a.hvtab[hv < HV ? hv : HV - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < NVM; ++k) {
+      const int hv = v0 + k * 32;
+      const int cx = cx0 + (pkk[k] & 511), cy = cy0 + ((pkk[k] >> 9) & 511), cz = cz0 + ((pkk[k] >> 18) & 255);
+      const bool ok = hv < HV && b0 < a.B && cz >= 0 && cz < Zc && cy >= 0 && cy < Yc && cx >= 0 && cx < Xc;
+      soff[k] = ok ? ((b0 * a.Zs + (cz >> a.ups)) * a.Ys + (cy >> a.ups)) * a.Xs + (cx >> a.ups) : 0;
+      okmask |= (ok ? 1u : 0u) << k;
+    }
+  }
+
+  CM_RT(1)
+  for (int ch = ch0; ch < ch1; ++ch) {
     const float *src;
     int Cs, c0, cg0;
     if (ch < a.nch0) { src = a.src0; Cs = a.C0; c0 = ch * a.CK; cg0 = c0; }
@@ -167,7 +205,26 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       sc1 = *reinterpret_cast<const f32x4 *>(g);
       sh1 = *reinterpret_cast<const f32x4 *>(g + Ctot);
     }
-    for (int hv0 = v0; hv0 < HV && !(a.dbg & 1); hv0 += vstep * SU) {
+    if (fstage && !(a.dbg & 1)) {
+      f32x4 v[NVM];
+#pragma unroll
+      for (int k = 0; k < NVM; ++k)
+        if (k * 32 < HV) v[k] = *reinterpret_cast<const f32x4 *>(srcq + (size_t)soff[k] * Cs);
+#pragma unroll
+      for (int k = 0; k < NVM; ++k) {
+        const int hv = v0 + k * 32;
+        if (k * 32 < HV) {
+          f32x4 w = v[k];
+          if (a.gn && !(a.dbg & 128)) {
+            w = w * sc1 + sh1;
+            if (a.silu) { w[0] = silu_f(w[0]); w[1] = silu_f(w[1]); w[2] = silu_f(w[2]); w[3] = silu_f(w[3]); }
+          }
+          if (!((okmask >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (hv < HV) *reinterpret_cast<f32x4 *>(&A[hv * S + 4 * q4]) = w;
+        }
+      }
+    }
+    for (int hv0 = v0; hv0 < HV && !(a.dbg & 1) && !fstage; hv0 += vstep * SU) {
       int pk[SU];
       f32x4 v[SU];
       int bbv[SU];
@@ -206,6 +263,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       }
     }
     __syncthreads();
+    if (ch == ch0) { CM_RT(2) }
     // ---- this wave's share of the (tap, 8-channel) steps ---------------------
     if (a.dbg & 2) continue;
     if constexpr (fast) {
@@ -246,7 +304,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
           // refill this ring slot with the fragments PD taps ahead (possibly next chunk)
           int tn = t + PD, chn = ch;
           if (tn >= TAPS) { tn -= TAPS; chn += 1; }
-          if (chn < nchunks) {
+          if (chn < ch1) {
             const f32x4 *wp = (a.dbg & 64) ? wtile : wtile + ((size_t)chn * (TAPS * 4) + (wave + 4 * tn)) * NB * 64;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) bq[d][nb] = wp[nb * 64];
@@ -287,6 +345,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
   }
 
+  CM_RT(3)
   // ---- cross-wave reduction (rounds of RB blocks) + epilogue -------------------
   if (a.dbg & 4) {
     if (acc[0][0][0] == 123.456f) a.out[0] = 1.f;  // keep the accumulators live
@@ -361,7 +420,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
           }
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg)
-            if (nok && offs[reg] >= 0) a.out[(size_t)offs[reg] * a.out_cs + n] = rs[reg];
+            if (nok && offs[reg] >= 0) outp[(size_t)offs[reg] * a.out_cs + n] = rs[reg];
           if (a.stat_part && !(a.dbg & 256)) {
             // fused GroupNorm statistics of this 32-row block (two-pass on registers, the
             // two lane halves merged with one cross-lane exchange): layers.py:30,41 read them
@@ -387,6 +446,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
           }
         }
       }
+    }
+  }
+  if ((a.dbg & 8) && tid == 0 && a.dbg_buf) {
+    tst[4] = __builtin_amdgcn_s_memrealtime();
+    const size_t w = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (w < 8192) {
+      unsigned long long *d = reinterpret_cast<unsigned long long *>(a.dbg_buf) + w * 8;
+      for (int i = 0; i < 5; ++i) d[i] = tst[i];
     }
   }
 }
@@ -447,16 +514,42 @@ bool conv_variant_exists(int MB, int NB) {
   return false;
 }
 
+static void conv_dbg_report(const ConvArgs &a, int MB, int NB, int F, dim3 grid, unsigned long long *buf, hipStream_t st) {
+  static int shown = 0;
+  (void)hipStreamSynchronize(st);
+  if (shown++ >= 60) return;
+  const size_t nwg = std::min<size_t>((size_t)grid.x * grid.y * grid.z, 8192);
+  std::vector<unsigned long long> h(nwg * 8);
+  (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
+  unsigned long long t0 = ~0ull, t1 = 0;
+  double ph[4] = {0, 0, 0, 0};
+  for (size_t w = 0; w < nwg; ++w) {
+    if (!h[w * 8]) continue;
+    t0 = std::min(t0, h[w * 8]); t1 = std::max(t1, h[w * 8 + 4]);
+    for (int i = 0; i < 4; ++i) ph[i] += (double)(h[w * 8 + i + 1] - h[w * 8 + i]) / nwg;
+  }
+  fprintf(stderr, "conv<%d,%d,%d> Ci=%d Co=%d taps=%d ks=%d grid=%ux%ux%u: span %.1f us | per WG (us): setup %.2f first-stage %.2f chunks(mfma+stage) %.2f reduce+epilogue %.2f\n",
+          MB, NB, F, a.C0 + a.C1, a.Co, a.ntaps, a.ks, grid.x, grid.y, grid.z, (t1 - t0) / 100.0, ph[0] / 100, ph[1] / 100, ph[2] / 100, ph[3] / 100);
+}
+
 hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
   static const int dbg = getenv("CM_CONV_DBG") ? atoi(getenv("CM_CONV_DBG")) : 0;  // ablation switches (perf studies only)
   static const int stg = getenv("CM_CONV_STAGGER") ? atoi(getenv("CM_CONV_STAGGER")) : -1;
   ConvArgs a = a_in;
   a.dbg = dbg;
   if (stg >= 0) a.stagger = stg;
+  static unsigned long long *dbgbuf = nullptr;
+  if (dbg & 8) {
+    if (!dbgbuf) (void)hipMalloc((void **)&dbgbuf, 8192 * 8 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dbgbuf, 0, 8192 * 8 * sizeof(unsigned long long), st);
+    a.dbg_buf = reinterpret_cast<float *>(dbgbuf);
+  }
   const size_t lds = conv_lds_bytes(a, MB, NB);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int TN = 32 * NB;
-  dim3 grid((unsigned)(a.nts * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + TN - 1) / TN), a.par ? 8u : 1u);
+  if (a.par && a.ks > 1) return hipErrorInvalidValue;
+  dim3 grid((unsigned)(a.nts * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + TN - 1) / TN),
+            a.par ? 8u : (a.ks > 1 ? (unsigned)a.ks : 1u));
   const int fastk = (a.CK == 32 && (a.ntaps == 27 || a.ntaps == 8)) ? a.ntaps : 0;
 #define CM_LAUNCH(m, n, f)                                                                       \
   {                                                                                              \
@@ -470,6 +563,7 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
       attr_set[dev & 63] = true;                                                                 \
     }                                                                                            \
     hipLaunchKernelGGL((conv_mfma_kernel<m, n, f>), grid, dim3(256), lds, st, a);                \
+    if (dbg & 8) conv_dbg_report(a, m, n, f, grid, dbgbuf, st);                                  \
     return hipGetLastError();                                                                    \
   }
 #define X(m, n)                                    \

@@ -38,6 +38,9 @@ struct ConvArgs {
   int par;             // 1: nearest-x2-upsample + 3x3x3 conv evaluated as 8 parity classes of 2x2x2
                        //    convs on the low-resolution source (gridDim.z = 8); output voxel = 2*i + parity
   long long wpar_stride;  // floats between the packed weight sets of consecutive parities
+  int ks;              // > 1: K is split over gridDim.z workgroups (chunk ranges); each writes its RAW partial
+                       //      sums to out + z * kpart (bias / temb / residual / statistics happen in ksplit_combine)
+  long long kpart;     // floats between consecutive partial outputs
   int stride;          // 1 or 2
   int ups;             // 1: source is nearest-upsampled x2 on the fly
   int bs, bz, by, bx;  // output box of one workgroup: samples x z x y x x
@@ -82,6 +85,16 @@ hipError_t launch_chan_stats(const float *x, int B, int V, int C, int nslice, fl
 hipError_t launch_gn_finalize(const float *part0, const float *cnt0, int ns0, int C0, const float *part1,
                               const float *cnt1, int ns1, int C1, int V, const float *gamma, const float *beta,
                               int groups, float eps, float *gn, int B, hipStream_t st);
+// Second pass of a K-split convolution: out = sum_s part[s] (fixed order) + bias + temb + residual,
+// plus the GroupNorm statistics of out per 32-row slot.  part: [S][B][V][C], C <= 256.
+struct CombineArgs {
+  const float *part; int S; long long stride;
+  const float *bias; const float *temb; int temb_stride; const long long *tidx;
+  const float *resid; int res_cs;
+  float *out; int C, V, B;
+  float *stat_part; float *stat_cnt; int nslots;
+};
+hipError_t launch_ksplit_combine(const CombineArgs &a, hipStream_t st);
 // reference layout [B,C,H,W,P] + [B,C,H,W,F]  ->  channels-last [B][P+F][H][W][8]
 hipError_t launch_assemble_input(const float *past, const float *future, float *x8, int B, int C, int H, int W,
                                  int P, int F, int which /*1 past,2 future,3 both*/, hipStream_t st);

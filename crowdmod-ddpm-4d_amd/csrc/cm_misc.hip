@@ -164,6 +164,75 @@ hipError_t launch_gn_finalize(const float *part0, const float *cnt0, int ns0, in
 }
 
 // --------------------------------------------------------------------------------
+// Second pass of a K-split convolution (tiny-spatial layers, cm_conv.hip ks > 1): sums the
+// S raw partial outputs in a fixed order, applies the conv epilogue (bias, time-embedding
+// row, residual) and produces the GroupNorm statistics of the result per 32-row slot.
+// grid (nslots, B), 256 threads = C channels x (256/C) row lanes; C <= 256.
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ksplit_combine_kernel(const CombineArgs a) {
+  __shared__ float red[256];
+  const int slot = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int nl = 256 / a.C > 0 ? 256 / a.C : 1;
+  const int c = tid % a.C, rl = tid / a.C;
+  const bool act = rl < nl;
+  const int r0 = slot * 32, r1 = min(a.V, r0 + 32);
+  float add = 0.f;
+  if (act) {
+    add = a.bias[c];
+    if (a.temb) add += a.temb[(size_t)a.tidx[b] * a.temb_stride + c];
+  }
+  float vals[32];
+  float s1 = 0.f, cnt = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int row = r0 + rl + i * nl;
+    vals[i] = 0.f;
+    if (act && i * nl < 32 && row < r1) {
+      const size_t idx = ((size_t)b * a.V + row) * a.C + c;
+      float v = 0.f;
+      for (int s = 0; s < a.S; ++s) v += a.part[(size_t)s * a.stride + idx];
+      v += add;
+      if (a.resid) v += a.resid[((size_t)b * a.V + row) * a.res_cs + c];
+      a.out[idx] = v;
+      vals[i] = v;
+      s1 += v;
+      cnt += 1.f;
+    }
+  }
+  if (!a.stat_part) return;
+  // per-channel statistics of the slot: merge the row lanes through LDS (fixed order)
+  red[tid] = s1;
+  __syncthreads();
+  float tot = 0.f;
+  for (int l = 0; l < nl; ++l) tot += red[l * a.C + c];
+  const float n = (float)(r1 - r0);
+  const float mean = tot / n;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int row = r0 + rl + i * nl;
+    if (act && i * nl < 32 && row < r1) { const float d = vals[i] - mean; q += d * d; }
+  }
+  __syncthreads();
+  red[tid] = q;
+  __syncthreads();
+  if (act && rl == 0) {
+    float m2 = 0.f;
+    for (int l = 0; l < nl; ++l) m2 += red[l * a.C + c];
+    float *sp = a.stat_part + (((size_t)b * a.nslots + slot) * a.C + c) * 2;
+    sp[0] = mean;
+    sp[1] = m2;
+    if (c == 0) a.stat_cnt[(size_t)b * a.nslots + slot] = n;
+  }
+}
+
+hipError_t launch_ksplit_combine(const CombineArgs &a, hipStream_t st) {
+  if (a.C > 256 || a.C < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ksplit_combine_kernel, dim3(a.nslots, a.B), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
 // ABI edge: reference layout [B,C,H,W,L] <-> channels-last [B][L][H][W][8].
 // unet.py:138 (cat past||future on L) and unet.py:166 (keep frames >= P) are folded in.
 // --------------------------------------------------------------------------------

@@ -89,6 +89,9 @@ struct Op {
   int tuned_B = -1;
   int *d_hvtab = nullptr, *d_mtab = nullptr;  // device copies of the box coordinate tables
   Act *stat_act = nullptr;  // output tensor whose GroupNorm statistics this conv produces in its epilogue
+  int ks = 1;               // K split over workgroups (tiny-spatial layers) + combine pass
+  float *d_zero_bias = nullptr;
+  const Act *out_act = nullptr, *resid_act = nullptr;
   bool v2 = false;      // persistent pipelined kernel (cm_conv2.hip)
   int NW = 4, grid_x = 0;
   int *d_ctr = nullptr; // its tile counters
@@ -140,6 +143,8 @@ struct cm_model {
   long long *tbuf = nullptr;    // [B] timestep per sample
   float *temb_table = nullptr;  // [1000][nproj]
   int nproj = 0;
+  float *ks_scratch = nullptr;  // raw partial outputs of K-split convs [S][B][V][Co]
+  size_t ks_scratch_floats = 0;
   float *xstate = nullptr;      // sampler state [B,C,H,W,F]
   float *stage_past = nullptr, *stage_fut = nullptr, *stage_out = nullptr;  // host-variant staging
   float *stage_noise = nullptr;
@@ -369,7 +374,10 @@ void pick_tile(Op &op, int B) {
   const int osd = a.par ? 2 : 1;  // parity mode tiles the low-resolution source grid
   const int Zo = a.Zo / osd, Yo = a.Yo / osd, Xo = a.Xo / osd;
   const int vox = Zo * Yo * Xo;
-  const int max_blk = (NB == 1) ? 8 : (NB == 2 ? 4 : 2);
+  // largest accumulator blocking that still fits 256 VGPRs (2 waves/SIMD) without spilling;
+  // the register-ring fast path (CK == 32) carries more live state than the generic one
+  const bool fastp = a.CK == 32 && (a.ntaps == 27 || a.ntaps == 8);
+  const int max_blk = fastp ? ((NB == 1) ? 5 : (NB == 2 ? 2 : 1)) : ((NB == 1) ? 8 : (NB == 2 ? 4 : 2));
   double best = -1;
   int bbs = 1, bbz = 1, bby = 1, bbx = 1, bMB = 1;
   const int ntn = (a.Co + 32 * NB - 1) / (32 * NB);
@@ -498,6 +506,10 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   // channels per workgroup, up to 128); the K-split kernel keeps the rest
   op.v2 = (s.ntaps == 27 && !parity && a.CK == 32 && s.stride == 1 && s.out->V() >= 128 && getenv("CM_CONV2"));  // experimental
   op.NB = s.Co > 32 ? 2 : 1;
+  // tiny-spatial layers are overhead-bound, not throughput-bound: fewer, fatter workgroups
+  // (all 128 output channels per workgroup, K split over workgroups) amortise the per-workgroup
+  // fixed costs over 4x the matrix work
+  if (s.ntaps == 27 && s.out->V() <= 64 && s.Co % 128 == 0 && !getenv("CM_NO_FAT_TILES")) op.NB = 4;
   if (op.v2) {
     if (dev_alloc(m, (void **)&op.d_ctr, 64 * sizeof(int))) return 1;
     CM_HIP(hipMemset(op.d_ctr, 0, 64 * sizeof(int)));
@@ -529,6 +541,20 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   if (upload(m, bp, &db)) return 1;
   a.wfrag = dw; a.bias = db;
   if (s.stats && !getenv("CM_NO_FUSED_STATS")) op.stat_act = s.out;
+  op.out_act = s.out;
+  op.resid_act = s.resid;
+  // Tiny-spatial layers (one 54-voxel tile per sample at quarter resolution): the only way to
+  // more parallelism AND less weight traffic per workgroup is to split K over workgroups;
+  // a second pass sums the partials in a fixed order and applies the epilogue.
+  const int nchunks = a.nch0 + a.nch1;
+  if (s.ntaps == 27 && !parity && a.CK == 32 && nchunks >= 2 && s.out->V() <= 64 && s.Co <= 256 && s.Co == s.out->C &&
+      op.stat_act && !getenv("CM_NO_KSPLIT")) {
+    op.ks = std::min(nchunks, 4);
+    const size_t need = (size_t)op.ks * m->cfg.max_batch * s.out->V() * s.Co;
+    m->ks_scratch_floats = std::max(m->ks_scratch_floats, need);
+    std::vector<float> zb((size_t)co_pad, 0.f);
+    if (upload(m, zb, &op.d_zero_bias)) return 1;
+  }
   op.flops_per_sample = 2.0 * s.out->V() * s.Co * (double)Ci_ref * s.ntaps;
   op.label = s.wname;
   m->ops.push_back(op);
@@ -709,6 +735,7 @@ int build_ops(cm_model *m) {
     ConvSpec cf; cf.s0 = h; cf.gn = gnf; cf.silu = 1; cf.wname = "final.2.weight"; cf.bname = "final.2.bias"; cf.out = eop; cf.Co = c.out_channels;
     if (add_conv(m, cf)) return 1;
   }
+  if (m->ks_scratch_floats && dev_alloc(m, (void **)&m->ks_scratch, m->ks_scratch_floats * sizeof(float))) return 1;
   return 0;
 }
 
@@ -784,7 +811,23 @@ int run_ops(cm_model *m, int B, hipStream_t st) {
           op.ca.stat_ns = ns;
           op.stat_act->nslots = ns;
         }
-        if (op.v2) {
+        if (op.ks > 1) {
+          cm::ConvArgs ka = op.ca;
+          const int V = op.out_act->V();
+          ka.temb = nullptr; ka.resid = nullptr; ka.stat_part = nullptr; ka.bias = op.d_zero_bias;
+          ka.out = m->ks_scratch; ka.out_cs = ka.Co;
+          ka.ks = op.ks; ka.kpart = (long long)B * V * ka.Co;
+          CM_HIP(cm::launch_conv(ka, op.MB, op.NB, st));
+          cm::CombineArgs cb{};
+          cb.part = m->ks_scratch; cb.S = op.ks; cb.stride = ka.kpart;
+          cb.bias = op.ca.bias; cb.temb = op.ca.temb; cb.temb_stride = op.ca.temb_stride; cb.tidx = op.ca.tidx;
+          cb.resid = op.ca.resid; cb.res_cs = op.ca.res_cs;
+          cb.out = op.ca.out; cb.C = ka.Co; cb.V = V; cb.B = B;
+          cb.nslots = (V + 31) / 32;
+          cb.stat_part = op.stat_act->part; cb.stat_cnt = op.stat_act->cnt;
+          op.stat_act->nslots = cb.nslots;
+          CM_HIP(cm::launch_ksplit_combine(cb, st));
+        } else if (op.v2) {
           const long tiles = (long)op.ca.ntz * op.ca.nty * op.ca.ntx * B;
           const int gx = (int)std::min<long>(tiles, op.grid_x);
           CM_HIP(cm::launch_conv2(op.ca, op.MB, op.NB, gx, op.d_ctr, st));
