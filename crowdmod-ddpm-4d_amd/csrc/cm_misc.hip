@@ -14,7 +14,7 @@ __device__ __forceinline__ void chan_combine(float &n, float &mean, float &m2, f
   if (nb == 0.f) return;
   const float nt = n + nb;
   const float d = meanb - mean;
-  const float f = nb / nt;
+  const float f = nb * __builtin_amdgcn_rcpf(nt);  // hardware reciprocal (1 ulp) instead of an IEEE division
   mean += d * f;
   m2 += m2b + d * d * n * f;
   n = nt;

@@ -124,6 +124,8 @@ struct cm_model {
   cm_unet_config cfg{};
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};  // extra lanes of the batch interleave
+  hipEvent_t ev_join[4] = {nullptr, nullptr, nullptr, nullptr}, ev_fork = nullptr;
   std::vector<Param> params;
   std::map<std::string, int> pindex;
   std::vector<BlockDesc> enc, bott, dec;
@@ -735,7 +737,7 @@ int build_ops(cm_model *m) {
     ConvSpec cf; cf.s0 = h; cf.gn = gnf; cf.silu = 1; cf.wname = "final.2.weight"; cf.bname = "final.2.bias"; cf.out = eop; cf.Co = c.out_channels;
     if (add_conv(m, cf)) return 1;
   }
-  if (m->ks_scratch_floats && dev_alloc(m, (void **)&m->ks_scratch, m->ks_scratch_floats * sizeof(float))) return 1;
+  if (m->ks_scratch_floats && dev_alloc(m, (void **)&m->ks_scratch, 4 * m->ks_scratch_floats * sizeof(float))) return 1;
   return 0;
 }
 
@@ -772,7 +774,10 @@ int build_time_table(cm_model *m) {
 // ------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------
-int run_ops(cm_model *m, int B, hipStream_t st) {
+// Launch the op list for the `B` samples starting at sample `b0` on stream `st`.
+// Every sample-indexed pointer is offset by b0, so two disjoint sub-batches can run
+// concurrently on two streams (`slab` selects the stream's K-split scratch region).
+int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
   for (size_t oi = 0; oi < m->ops.size(); ++oi) {
     Op &op = m->ops[oi];
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -800,53 +805,74 @@ int run_ops(cm_model *m, int B, hipStream_t st) {
           op.ca.hvtab = op.d_hvtab;
           op.ca.mtab = op.d_mtab;
         }
-        op.ca.B = B;
-        op.ca.nts = (B + op.ca.bs - 1) / op.ca.bs;
+        cm::ConvArgs ca = op.ca;
+        ca.B = B;
+        ca.nts = (B + ca.bs - 1) / ca.bs;
+        const size_t Vs = (size_t)ca.Zs * ca.Ys * ca.Xs, Vo = (size_t)ca.Zo * ca.Yo * ca.Xo;
+        ca.src0 += (size_t)b0 * Vs * ca.C0;
+        if (ca.src1) ca.src1 += (size_t)b0 * Vs * ca.C1;
+        if (ca.gn) ca.gn += (size_t)b0 * 2 * (ca.C0 + ca.C1);
+        ca.tidx += b0;
+        if (ca.resid) ca.resid += (size_t)b0 * Vo * ca.res_cs;
+        ca.out += (size_t)b0 * Vo * ca.out_cs;
+        int ns = 0;
         if (op.stat_act) {
-          const int ns = op.ca.ntz * op.ca.nty * op.ca.ntx * op.MB * (op.ca.par ? 8 : 1);
+          ns = ca.ntz * ca.nty * ca.ntx * op.MB * (ca.par ? 8 : 1);
           if (ns > MAX_SLOTS) return fail("statistics slots %d exceed %d", ns, MAX_SLOTS);
-          op.ca.stat_part = op.stat_act->part;
-          op.ca.stat_cnt = op.stat_act->cnt;
-          op.ca.stat_C = op.stat_act->C;
-          op.ca.stat_ns = ns;
+          ca.stat_C = op.stat_act->C;
+          ca.stat_ns = ns;
+          ca.stat_part = op.stat_act->part + (size_t)b0 * ns * ca.stat_C * 2;
+          ca.stat_cnt = op.stat_act->cnt + (size_t)b0 * ns;
           op.stat_act->nslots = ns;
         }
         if (op.ks > 1) {
-          cm::ConvArgs ka = op.ca;
+          cm::ConvArgs ka = ca;
           const int V = op.out_act->V();
+          float *scratch = m->ks_scratch + (size_t)slab * m->ks_scratch_floats;
           ka.temb = nullptr; ka.resid = nullptr; ka.stat_part = nullptr; ka.bias = op.d_zero_bias;
-          ka.out = m->ks_scratch; ka.out_cs = ka.Co;
+          ka.out = scratch; ka.out_cs = ka.Co;
           ka.ks = op.ks; ka.kpart = (long long)B * V * ka.Co;
           CM_HIP(cm::launch_conv(ka, op.MB, op.NB, st));
           cm::CombineArgs cb{};
-          cb.part = m->ks_scratch; cb.S = op.ks; cb.stride = ka.kpart;
-          cb.bias = op.ca.bias; cb.temb = op.ca.temb; cb.temb_stride = op.ca.temb_stride; cb.tidx = op.ca.tidx;
-          cb.resid = op.ca.resid; cb.res_cs = op.ca.res_cs;
-          cb.out = op.ca.out; cb.C = ka.Co; cb.V = V; cb.B = B;
+          cb.part = scratch; cb.S = op.ks; cb.stride = ka.kpart;
+          cb.bias = ca.bias; cb.temb = ca.temb; cb.temb_stride = ca.temb_stride; cb.tidx = ca.tidx;
+          cb.resid = ca.resid; cb.res_cs = ca.res_cs;
+          cb.out = ca.out; cb.C = ka.Co; cb.V = V; cb.B = B;
           cb.nslots = (V + 31) / 32;
-          cb.stat_part = op.stat_act->part; cb.stat_cnt = op.stat_act->cnt;
+          cb.stat_part = op.stat_act->part + (size_t)b0 * cb.nslots * cb.C * 2;
+          cb.stat_cnt = op.stat_act->cnt + (size_t)b0 * cb.nslots;
           op.stat_act->nslots = cb.nslots;
           CM_HIP(cm::launch_ksplit_combine(cb, st));
         } else if (op.v2) {
-          const long tiles = (long)op.ca.ntz * op.ca.nty * op.ca.ntx * B;
+          const long tiles = (long)ca.ntz * ca.nty * ca.ntx * B;
           const int gx = (int)std::min<long>(tiles, op.grid_x);
-          CM_HIP(cm::launch_conv2(op.ca, op.MB, op.NB, gx, op.d_ctr, st));
+          CM_HIP(cm::launch_conv2(ca, op.MB, op.NB, gx, op.d_ctr + 32 * slab, st));
+        } else {
+          CM_HIP(cm::launch_conv(ca, op.MB, op.NB, st));
         }
-        else CM_HIP(cm::launch_conv(op.ca, op.MB, op.NB, st));
         break;
       }
-      case OP_STATS:
-        CM_HIP(cm::launch_chan_stats(op.act->d, B, op.act->V(), op.act->C, op.act->nslice, op.act->part, op.act->cnt, st));
-        const_cast<Act *>(op.act)->nslots = op.act->nslice;
+      case OP_STATS: {
+        const Act *t = op.act;
+        CM_HIP(cm::launch_chan_stats(t->d + (size_t)b0 * t->V() * t->C, B, t->V(), t->C, t->nslice,
+                                     t->part + (size_t)b0 * t->nslice * t->C * 2, t->cnt + (size_t)b0 * t->nslice, st));
+        const_cast<Act *>(t)->nslots = t->nslice;
         break;
-      case OP_GNFIN:
+      }
+      case OP_GNFIN: {
         if (op.g1 && op.g1->V() != op.g0->V()) return fail("concat sources disagree on voxel count");
-        CM_HIP(cm::launch_gn_finalize(op.g0->part, op.g0->cnt, op.g0->nslots, op.g0->C, op.g1 ? op.g1->part : nullptr,
-                                      op.g1 ? op.g1->cnt : nullptr, op.g1 ? op.g1->nslots : 0, op.g1 ? op.g1->C : 0,
-                                      op.g0->V(), op.gamma, op.beta, GN_GROUPS, GN_EPS, op.gn_out, B, st));
+        const Act *g0 = op.g0, *g1 = op.g1;
+        const int Ct = g0->C + (g1 ? g1->C : 0);
+        CM_HIP(cm::launch_gn_finalize(g0->part + (size_t)b0 * g0->nslots * g0->C * 2, g0->cnt + (size_t)b0 * g0->nslots,
+                                      g0->nslots, g0->C, g1 ? g1->part + (size_t)b0 * g1->nslots * g1->C * 2 : nullptr,
+                                      g1 ? g1->cnt + (size_t)b0 * g1->nslots : nullptr, g1 ? g1->nslots : 0,
+                                      g1 ? g1->C : 0, g0->V(), op.gamma, op.beta, GN_GROUPS, GN_EPS,
+                                      op.gn_out + (size_t)b0 * 2 * Ct, B, st));
         break;
+      }
       case OP_ATTN:
-        CM_HIP(cm::launch_attn_core(op.qkv, op.aout, B, op.S, op.E, ATTN_HEADS, st));
+        CM_HIP(cm::launch_attn_core(op.qkv + (size_t)b0 * op.S * 3 * op.E, op.aout + (size_t)b0 * op.S * op.E, B, op.S,
+                                    op.E, ATTN_HEADS, st));
         break;
     }
     if (m->profile) {
@@ -1003,6 +1029,11 @@ int cm_model_create(const cm_unet_config *cfg, cm_model **out) {
   build_plan(m.get());
   DevGuard g(m->device);
   CM_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  for (int i = 1; i < 4; ++i) {
+    CM_HIP(hipStreamCreateWithFlags(&m->lane_stream[i], hipStreamNonBlocking));
+    CM_HIP(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
+  }
+  CM_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
   *out = m.release();
   return 0;
 }
@@ -1013,6 +1044,11 @@ int cm_model_destroy(cm_model *m) {
   hipDeviceSynchronize();
   for (void *p : m->allocs) hipFree(p);
   if (m->stream) hipStreamDestroy(m->stream);
+  for (int i = 1; i < 4; ++i) {
+    if (m->lane_stream[i]) hipStreamDestroy(m->lane_stream[i]);
+    if (m->ev_join[i]) hipEventDestroy(m->ev_join[i]);
+  }
+  if (m->ev_fork) hipEventDestroy(m->ev_fork);
   delete m;
   return 0;
 }
@@ -1240,16 +1276,29 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
   const int last = s->T - 1;
   float beta_t = s->tab[CM_TAB_BETA][last], sab_t = s->tab[CM_TAB_SQRT_ALPHA_BAR][last],
         s1m_t = s->tab[CM_TAB_SQRT_ONE_MINUS_ALPHA_BAR][last];
+  // Two-way batch interleave: the chains are independent, so the batch is cut in two halves
+  // that run the whole step sequence on two streams.  Kernels of the two lanes overlap on the
+  // GPU -- the ramp-up / tail of one lane's launch is filled by the other lane's workgroups
+  // and their load / MFMA / store phases fall out of step -- with bit-identical results.
+  static const int want_lanes = getenv("CM_LANES") ? atoi(getenv("CM_LANES")) : 2;
+  int lanes = std::max(1, std::min(4, want_lanes));
+  if (B < 8 * lanes || m->profile || stream) lanes = 1;
+  int Bl[4], off[4];
+  hipStream_t sts[4] = {st, m->lane_stream[1], m->lane_stream[2], m->lane_stream[3]};
+  for (int ln = 0, o = 0; ln < lanes; ++ln) {
+    Bl[ln] = B / lanes + (ln < B % lanes ? 1 : 0);
+    off[ln] = o;
+    o += Bl[ln];
+  }
+  if (lanes > 1) {
+    CM_HIP(hipEventRecord(m->ev_fork, st));
+    for (int ln = 1; ln < lanes; ++ln) CM_HIP(hipStreamWaitEvent(sts[ln], m->ev_fork, 0));
+  }
   for (size_t k = 0; k < order.size(); ++k) {
     const int t = order[k];
-    CM_HIP(cm::launch_fill_t(m->tbuf, B, t, st));
-    if (run_ops(m, B, st)) return 1;
     cm::StepArgs a{};
-    a.x = m->xstate; a.eps_cl = m->eps_cl; a.cs = 8; a.x8 = m->x8;
-    a.B = B; a.C = c.in_channels; a.H = c.rows; a.W = c.cols; a.P = c.past_len; a.F = c.future_len;
-    a.seed = opts->seed; a.sample_id_base = opts->sample_id_base; a.step = t;
-    a.hist = d_history ? d_history + (k + 1) * B * per : nullptr;
-    a.noise = d_noise ? d_noise + k * B * per : nullptr;
+    a.C = c.in_channels; a.H = c.rows; a.W = c.cols; a.P = c.past_len; a.F = c.future_len;
+    a.seed = opts->seed; a.step = t; a.cs = 8;
     if (opts->sampler == CM_SAMPLER_DDIM) {
       const float sab_p = s->tab[CM_TAB_SQRT_ALPHA_BAR][t], s1m_p = s->tab[CM_TAB_SQRT_ONE_MINUS_ALPHA_BAR][t];
       const float sig = opts->ddim_sigma;
@@ -1264,8 +1313,25 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
       a.draw = t > 0;                                              // ddpm.py:27
       a.guid = opts->guidance == CM_GUIDANCE_SPARSITY ? opts->lambda_guidance * sqrtf(s->tab[CM_TAB_BETA][t]) : 0.f;
     }
-    if (a.draw == 0) a.noise = nullptr;
-    CM_HIP(cm::launch_sampler_step(a, st));
+    for (int ln = 0; ln < lanes; ++ln) {
+      const int b0 = off[ln], Bn = Bl[ln];
+      hipStream_t ls = sts[ln];
+      CM_HIP(cm::launch_fill_t(m->tbuf + b0, Bn, t, ls));
+      if (run_ops(m, Bn, ls, b0, ln)) return 1;
+      cm::StepArgs al = a;
+      al.B = Bn;
+      al.x = m->xstate + (size_t)b0 * per;
+      al.eps_cl = m->eps_cl + (size_t)b0 * m->L() * c.rows * c.cols * 8;
+      al.x8 = m->x8 + (size_t)b0 * m->L() * c.rows * c.cols * 8;
+      al.sample_id_base = opts->sample_id_base + b0;
+      al.hist = d_history ? d_history + (k + 1) * B * per + (size_t)b0 * per : nullptr;
+      al.noise = (d_noise && a.draw) ? d_noise + k * B * per + (size_t)b0 * per : nullptr;
+      CM_HIP(cm::launch_sampler_step(al, ls));
+    }
+  }
+  for (int ln = 1; ln < lanes; ++ln) {
+    CM_HIP(hipEventRecord(m->ev_join[ln], sts[ln]));
+    CM_HIP(hipStreamWaitEvent(st, m->ev_join[ln], 0));
   }
   CM_HIP(hipMemcpyAsync(d_out, m->xstate, B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
   return prof_collect(m, st);
