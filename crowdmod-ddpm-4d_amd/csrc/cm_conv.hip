@@ -199,7 +199,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     // LDS write; the hvtab entries beyond HV are clamped to the last valid one.
     // GroupNorm scale / shift of this thread's channel quad: one pair per chunk when the tile
     // holds a single sample (the common case), looked up per voxel otherwise
-    f32x4 sc1 = {1.f, 1.f, 1.f, 1.f}, sh1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 sc1 = {1.f, 1.f, 1.f, 1.f}, sh1 = {0.f, 0.f, 0.f, 0.f}, pm1 = {1.f, 1.f, 1.f, 1.f};
+    if (a.pm && a.bs == 1)
+      pm1 = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)(b0 < a.B ? b0 : 0) * a.pm_stride + cg0 + 4 * q4);
     if (a.gn && a.bs == 1) {
       const float *g = a.gn + (size_t)(b0 < a.B ? b0 : 0) * 2 * Ctot + cg0 + 4 * q4;
       sc1 = *reinterpret_cast<const f32x4 *>(g);
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             w = w * sc1 + sh1;
             if (a.silu) { w[0] = silu_f(w[0]); w[1] = silu_f(w[1]); w[2] = silu_f(w[2]); w[3] = silu_f(w[3]); }
           }
+          if (a.pm) w = w * pm1;
           if (!((okmask >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};
           if (hv < HV) *reinterpret_cast<f32x4 *>(&A[hv * S + 4 * q4]) = w;
         }
@@ -257,6 +260,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
           }
           w = w * sc + sh;
           if (a.silu) { w[0] = silu_f(w[0]); w[1] = silu_f(w[1]); w[2] = silu_f(w[2]); w[3] = silu_f(w[3]); }
+        }
+        if (a.pm) {
+          f32x4 pmv = pm1;
+          if (a.bs != 1) pmv = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)bbv[u] * a.pm_stride + cg0 + 4 * q4);
+          w = w * pmv;
         }
         if (!ok[u]) w = f32x4{0.f, 0.f, 0.f, 0.f};
         if (hv < HV) *reinterpret_cast<f32x4 *>(&A[hv * S + 4 * q4]) = w;

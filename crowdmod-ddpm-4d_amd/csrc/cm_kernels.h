@@ -20,6 +20,8 @@ struct ConvArgs {
   int C0, C1;          // multiples of CK
   const float *gn;     // [B][2][C0+C1] per-(sample,channel) scale row, shift row; or null
   int silu;            // apply SiLU after the affine (GroupNorm->SiLU fused on load)
+  const float *pm;     // optional per-(sample, input channel) multiplier applied after the activation:
+  int pm_stride;       //   the Dropout3d keep-mask / (1-p) of training mode (layers.py:42,71); row stride
   const float *wfrag;  // weights in MFMA fragment order (see pack_conv_weights)
   const float *bias;   // [Co padded to TN]
   const float *temb;   // [rows][temb_stride] time-embedding projection table, or null
@@ -128,6 +130,11 @@ hipError_t launch_sampler_step(const StepArgs &a, hipStream_t st);
 hipError_t launch_q_sample(const float *x0, const long long *t, const float *eps, const float *sab, const float *s1m,
                            float *xt, int B, long long per, hipStream_t st);
 hipError_t launch_fill_t(long long *t, int B, long long value, hipStream_t st);
+// mean((a-b)^2) over n elements -> *loss (single workgroup partials + deterministic final sum)
+hipError_t launch_mse_loss(const float *a, const float *b, long long n, float *partial, float *loss, hipStream_t st);
+// Dropout3d keep-mask / (1-p) per (sample, channel) from the device Philox stream
+hipError_t launch_dropout_mask(float *mask, int B, int C, float p, unsigned long long seed, long long sample_id_base,
+                               int step, hipStream_t st);
 hipError_t launch_randn(float *x, int B, long long per, unsigned long long seed, long long sample_id_base, int step,
                         hipStream_t st);
 // generic strided copy channels-last -> reference layout (debug hook)

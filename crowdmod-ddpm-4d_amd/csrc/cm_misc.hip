@@ -559,6 +559,61 @@ hipError_t launch_q_sample(const float *x0, const long long *t, const float *eps
   return hipGetLastError();
 }
 
+// mean squared error, F.mse_loss(reduction='mean') (ddpm.py:120): per-workgroup partial sums in
+// a fixed order, final sum by one thread -> deterministic.
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                          long long n, float *__restrict__ partial) {
+  __shared__ float sh[256];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float d = a[i] - b[i];
+    acc = fmaf(d, d, acc);
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+__global__ void mse_final_kernel(const float *__restrict__ partial, int np, long long n, float *__restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < np; ++i) s += (double)partial[i];
+    *loss = (float)(s / (double)n);
+  }
+}
+
+hipError_t launch_mse_loss(const float *a, const float *b, long long n, float *partial, float *loss, hipStream_t st) {
+  const int np = 64;
+  hipLaunchKernelGGL(mse_partial_kernel, dim3(np), dim3(256), 0, st, a, b, n, partial);
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, st, partial, np, n, loss);
+  return hipGetLastError();
+}
+
+// Dropout3d (layers.py:42,71) zeroes whole (sample, channel) volumes with probability p and
+// scales the survivors by 1/(1-p).
+__global__ void dropout_mask_kernel(float *__restrict__ mask, int B, int C, float p, unsigned long long seed,
+                                    long long sample_id_base, int step) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  unsigned r[4];
+  philox4x32_10((unsigned)c, (unsigned)(sample_id_base + b), (unsigned)step, 0xD120u, (unsigned)seed,
+                (unsigned)(seed >> 32), r);
+  const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  mask[i] = (u >= p) ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+hipError_t launch_dropout_mask(float *mask, int B, int C, float p, unsigned long long seed, long long sample_id_base,
+                               int step, hipStream_t st) {
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, mask, B, C, p, seed,
+                     sample_id_base, step);
+  return hipGetLastError();
+}
+
 __global__ void fill_t_kernel(long long *t, int B, long long v) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < B) t[i] = v;

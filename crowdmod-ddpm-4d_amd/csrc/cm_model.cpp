@@ -89,6 +89,7 @@ struct Op {
   int tuned_B = -1;
   int *d_hvtab = nullptr, *d_mtab = nullptr;  // device copies of the box coordinate tables
   Act *stat_act = nullptr;  // output tensor whose GroupNorm statistics this conv produces in its epilogue
+  int pm_off = -1;          // >= 0: conv_2 of a ResnetBlock; offset of its Dropout3d mask row slice (training forward)
   int ks = 1;               // K split over workgroups (tiny-spatial layers) + combine pass
   float *d_zero_bias = nullptr;
   const Act *out_act = nullptr, *resid_act = nullptr;
@@ -145,6 +146,9 @@ struct cm_model {
   long long *tbuf = nullptr;    // [B] timestep per sample
   float *temb_table = nullptr;  // [1000][nproj]
   int nproj = 0;
+  float *dropmask = nullptr;    // [B][nproj] Dropout3d keep-mask/(1-p) of the current training forward
+  bool train_fwd = false;
+  float *mse_partial = nullptr, *mse_loss = nullptr;
   float *ks_scratch = nullptr;  // raw partial outputs of K-split convs [S][B][V][Co]
   size_t ks_scratch_floats = 0;
   float *xstate = nullptr;      // sampler state [B,C,H,W,F]
@@ -475,6 +479,7 @@ struct ConvSpec {
   int Co = 0;
   int ci_valid = -1;  // valid input channels of the reference weight (first conv: 3 of 8)
   bool stats = false; // produce the GroupNorm statistics of `out` in the epilogue
+  int pm_off = -1;    // Dropout3d mask slice of the input (conv_2 of a ResnetBlock)
 };
 
 int add_conv(cm_model *m, const ConvSpec &s) {
@@ -545,6 +550,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   if (s.stats && !getenv("CM_NO_FUSED_STATS")) op.stat_act = s.out;
   op.out_act = s.out;
   op.resid_act = s.resid;
+  op.pm_off = s.pm_off;
   // Tiny-spatial layers (one 54-voxel tile per sample at quarter resolution): the only way to
   // more parallelism AND less weight traffic per workgroup is to split K over workgroups;
   // a second pass sums the partials in a fixed order and applies the epilogue.
@@ -646,7 +652,7 @@ int build_ops(cm_model *m) {
     Act *h2 = new_act(m, b.attention ? p + ".conv_2+skip" : p, b.cout, Zl[l], Yl[l], Xl[l], true, &rc);
     if (rc) return 1;
     ConvSpec c2; c2.s0 = h1; c2.gn = gn2; c2.silu = 1; c2.wname = p + ".conv_2.weight"; c2.bname = p + ".conv_2.bias";
-    c2.resid = resid; c2.out = h2; c2.Co = b.cout; c2.stats = true;
+    c2.resid = resid; c2.out = h2; c2.Co = b.cout; c2.stats = true; c2.pm_off = temb_off[p];
     if (add_conv(m, c2)) return 1;
     add_stats(m, h2);
     *result = h2;
@@ -813,6 +819,10 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
         if (ca.src1) ca.src1 += (size_t)b0 * Vs * ca.C1;
         if (ca.gn) ca.gn += (size_t)b0 * 2 * (ca.C0 + ca.C1);
         ca.tidx += b0;
+        if (m->train_fwd && op.pm_off >= 0) {
+          ca.pm = m->dropmask + (size_t)b0 * m->nproj + op.pm_off;
+          ca.pm_stride = m->nproj;
+        }
         if (ca.resid) ca.resid += (size_t)b0 * Vo * ca.res_cs;
         ca.out += (size_t)b0 * Vo * ca.out_cs;
         int ns = 0;
@@ -1106,6 +1116,9 @@ int cm_model_finalize(cm_model *m) {
   const size_t per = (size_t)m->per_sample();
   const size_t per_past = (size_t)c.in_channels * c.rows * c.cols * c.past_len;
   if (dev_alloc(m, (void **)&m->xstate, B * per * sizeof(float))) return 1;
+  if (dev_alloc(m, (void **)&m->dropmask, B * (size_t)m->nproj * sizeof(float))) return 1;
+  if (dev_alloc(m, (void **)&m->mse_partial, 64 * sizeof(float))) return 1;
+  if (dev_alloc(m, (void **)&m->mse_loss, sizeof(float))) return 1;
   if (dev_alloc(m, (void **)&m->stage_fut, B * per * sizeof(float))) return 1;
   if (dev_alloc(m, (void **)&m->stage_out, B * per * sizeof(float))) return 1;
   if (dev_alloc(m, (void **)&m->stage_past, B * per_past * sizeof(float))) return 1;
@@ -1152,6 +1165,47 @@ int cm_unet_forward_host(cm_model *m, const float *h_future, const int64_t *h_t,
   hipFree(dt);
   if (rc) return rc;
   CM_HIP(hipMemcpy(h_out, m->stage_out, B * per * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int cm_model_dropout_width(const cm_model *m, int32_t *width) {
+  if (!m || !width) return fail("null argument");
+  if (!m->finalized) return fail("model not finalized");
+  *width = m->nproj;
+  return 0;
+}
+
+int cm_unet_forward_train(cm_model *m, const float *d_future, const int64_t *d_t, const float *d_past,
+                          const float *d_dropmask, float p, uint64_t seed, int64_t sample_id_base, float *d_out,
+                          int32_t B, void *stream) {
+  if (check_ready(m, B)) return 1;
+  if (!d_future || !d_t || !d_past || !d_out) return fail("null tensor argument");
+  if (!(p >= 0.f && p < 1.f)) return fail("dropout rate %g outside [0,1)", p);
+  DevGuard g(m->device);
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  const cm_unet_config &c = m->cfg;
+  if (d_dropmask)
+    CM_HIP(hipMemcpyAsync(m->dropmask, d_dropmask, (size_t)B * m->nproj * sizeof(float), hipMemcpyDeviceToDevice, st));
+  else
+    CM_HIP(cm::launch_dropout_mask(m->dropmask, B, m->nproj, p, seed, sample_id_base, 0, st));
+  CM_HIP(hipMemcpyAsync(m->tbuf, d_t, (size_t)B * sizeof(long long), hipMemcpyDeviceToDevice, st));
+  CM_HIP(cm::launch_assemble_input(d_past, d_future, m->x8, B, c.in_channels, c.rows, c.cols, c.past_len, c.future_len, 3, st));
+  m->train_fwd = true;
+  const int rc = run_ops(m, B, st);
+  m->train_fwd = false;
+  if (rc) return 1;
+  CM_HIP(cm::launch_extract_output(m->eps_cl, 8, d_out, B, c.out_channels, c.rows, c.cols, c.past_len, c.future_len, st));
+  return 0;
+}
+
+int cm_mse_loss(cm_model *m, const float *d_pred, const float *d_target, int64_t n, float *h_loss, void *stream) {
+  if (!m || !d_pred || !d_target || !h_loss || n < 1) return fail("bad argument");
+  if (!m->finalized) return fail("model not finalized");
+  DevGuard g(m->device);
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  CM_HIP(cm::launch_mse_loss(d_pred, d_target, n, m->mse_partial, m->mse_loss, st));
+  CM_HIP(hipMemcpyAsync(h_loss, m->mse_loss, sizeof(float), hipMemcpyDeviceToHost, st));
+  CM_HIP(hipStreamSynchronize(st));
   return 0;
 }
 

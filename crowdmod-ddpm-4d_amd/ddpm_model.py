@@ -151,6 +151,25 @@ class DDPM_model:
         return x, [x_T, x]
 
     # ------------------------------------------------------------------------------
+    def _train_step(self, future, past, forward_sampler: DDPM, *, t=None, noise=None, drop_masks=None,
+                    rng: Optional[np.random.Generator] = None):
+        """Forward half of ddpm.py:111-121: t ~ U{0..T-1}, (x_t, eps) = q_sample(future, t),
+        eps_hat = UNet(x_t, t, past) with Dropout3d active, loss = mse(eps_hat, eps).
+        Returns (loss, eps_hat).  The backward pass and the Adam update (ddpm.py:142-144) are
+        NOT implemented in this build: the value is the loss of the current weights only."""
+        future = np.ascontiguousarray(future, dtype=np.float32)
+        B = future.shape[0]
+        if t is None:
+            rng = rng or np.random.default_rng(self.seed)
+            t = rng.integers(0, forward_sampler.timesteps, size=(B,))
+        x_t, eps = forward_sampler(future, t, noise=noise)
+        self.denoiser.train()
+        try:
+            pred = self.denoiser.forward_train(x_t, t, past, drop_masks=drop_masks, seed=self.seed)
+        finally:
+            self.denoiser.eval()
+        return self.denoiser.mse_loss(pred, eps), pred
+
     def load_checkpoint(self, model_fullname: str):
         """ddpm.py:288: load_state_dict(torch.load(path, map_location='cpu', weights_only=True)['model'])."""
         from . import checkpoint

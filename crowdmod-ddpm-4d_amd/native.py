@@ -68,6 +68,9 @@ SIGNATURES = {
     "cm_model_finalize": (C.c_int, [_P]),
     "cm_unet_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P]),
     "cm_unet_forward_host": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
+    "cm_model_dropout_width": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "cm_unet_forward_train": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_uint64, C.c_int64, _P, C.c_int32, _P]),
+    "cm_mse_loss": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_float), _P]),
     "cm_debug_activation": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "cm_schedule_create": (C.c_int, [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, C.POINTER(_P)]),
     "cm_schedule_destroy": (C.c_int, [_P]),

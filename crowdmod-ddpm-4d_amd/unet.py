@@ -140,7 +140,7 @@ class UNet:
         if past is None:
             raise ValueError("condition='Past' needs the past frames")
         if self.training:
-            raise NotImplementedError("training-mode forward (Dropout3d) is not part of this build yet")
+            return self.forward_train(future, t, past)
         L = native.lib()
         B, Cc, H, W, F = (int(v) for v in future.shape)
         P = int(past.shape[4])
@@ -167,6 +167,50 @@ class UNet:
         out = np.empty_like(fut)
         native.check(L.cm_unet_forward_host(h, fut.ctypes.data, tt.ctypes.data, pst.ctypes.data, out.ctypes.data, B))
         return out
+
+    def dropout_layout(self):
+        """[(prefix, offset, Cout)] of the per-block slices of the training-mode mask row."""
+        plan = spec.make_plan(self.cfg)
+        out, off = [], 0
+        for b in plan.res_blocks():
+            out.append((b.prefix, off, b.cout))
+            off += b.cout
+        return out, off
+
+    def forward_train(self, future, t, past, drop_masks=None, seed: int = 0, sample_id_base: int = 0):
+        """Training-mode forward (Dropout3d active, layers.py:42,71).  `drop_masks` maps a
+        ResnetBlock prefix to its [B, Cout] keep-mask/(1-p); None draws the masks on the device.
+        numpy in -> numpy out."""
+        L = native.lib()
+        fut = np.ascontiguousarray(future, dtype=np.float32)
+        pst = np.ascontiguousarray(past, dtype=np.float32)
+        B, Cc, H, W, F = fut.shape
+        P = pst.shape[4]
+        h = self.ensure(H, W, P, F, B)
+        tt = np.ascontiguousarray(np.broadcast_to(np.asarray(t, dtype=np.int64).reshape(-1), (B,)))
+        dev = self.device
+        dfut, dpst, dt = (native.DeviceBuffer.from_array(a, dev) for a in (fut, pst, tt))
+        dout = native.DeviceBuffer(fut.nbytes, dev)
+        dmask = None
+        if drop_masks is not None:
+            layout, width = self.dropout_layout()
+            row = np.ones((B, width), dtype=np.float32)
+            for prefix, off, cout in layout:
+                row[:, off:off + cout] = np.asarray(drop_masks[prefix], dtype=np.float32)
+            dmask = native.DeviceBuffer.from_array(row, dev)
+        native.check(L.cm_unet_forward_train(h, dfut.ptr, dt.ptr, dpst.ptr, dmask.ptr if dmask else None,
+                                             float(self.cfg.dropout_rate), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                             int(sample_id_base), dout.ptr, B, None))
+        native.check(L.cm_device_synchronize(dev))
+        return dout.download(fut.shape)
+
+    def mse_loss(self, pred, target) -> float:
+        """F.mse_loss(pred, target) on the device (ddpm.py:120)."""
+        a = native.DeviceBuffer.from_array(np.ascontiguousarray(pred, dtype=np.float32), self.device)
+        b = native.DeviceBuffer.from_array(np.ascontiguousarray(target, dtype=np.float32), self.device)
+        out = C.c_float()
+        native.check(native.lib().cm_mse_loss(self._handle, a.ptr, b.ptr, int(np.asarray(pred).size), C.byref(out), None))
+        return float(out.value)
 
     def debug_activation(self, name: str) -> np.ndarray:
         """Activation of the last forward by reference module name, layout [B,C,H,W,L]

@@ -91,6 +91,18 @@ int cm_unet_forward(cm_model *m, const float *d_future, const int64_t *d_t, cons
 /* Same with host buffers (staged through the workspace; synchronous). */
 int cm_unet_forward_host(cm_model *m, const float *h_future, const int64_t *h_t, const float *h_past,
                          float *h_out, int32_t B);
+/* Training-mode forward -- unet.py:124-167 with nn.Dropout3d active (layers.py:42,71): one
+ * keep-mask/(1-p) value per (sample, ResnetBlock, channel).  d_dropmask [B][width] injects the
+ * masks (width from cm_model_dropout_width: the blocks in state_dict order, Cout entries each);
+ * NULL draws them from the device Philox stream (seed, sample_id_base + b).  Used by
+ * DDPM_model._train_step (ddpm.py:111-121); the backward pass is not part of this build yet. */
+int cm_model_dropout_width(const cm_model *m, int32_t *width);
+int cm_unet_forward_train(cm_model *m, const float *d_future, const int64_t *d_t, const float *d_past,
+                          const float *d_dropmask, float p, uint64_t seed, int64_t sample_id_base,
+                          float *d_out, int32_t B, void *stream);
+/* F.mse_loss(pred, target) with reduction='mean' (ddpm.py:120); the scalar lands in *h_loss. */
+int cm_mse_loss(cm_model *m, const float *d_pred, const float *d_target, int64_t n, float *h_loss,
+                void *stream);
 /* Test hook: copy an internal activation (by reference module name, e.g.
  * "encoder_blocks.0") of the last forward to the host in reference layout
  * [B,C,H,W,L].  `shape` receives {B,C,H,W,L}. */

@@ -180,3 +180,38 @@ def test_device_rng_is_shard_independent_and_normal():
     assert np.array_equal(full[:2], lo) and np.array_equal(full[2:], hi)
     xT = hist[0]
     assert abs(float(xT.mean())) < 0.05 and abs(float(xT.std()) - 1.0) < 0.05
+
+
+def test_training_forward_and_loss_vs_reference():
+    """Forward half of DDPM_model._train_step (ddpm.py:111-121) on the narrow model: q-sample,
+    UNet in train mode with the Dropout3d masks injected, MSE -- against the loss and the
+    prediction the reference produced for the same t / eps / masks."""
+    from crowdmod_ddpm_4d_amd.config import AttrDict
+    from crowdmod_ddpm_4d_amd.ddpm_model import DDPM_model
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    g = load("train.npz")
+    C_, B = 3, 4
+    cfg = AttrDict({
+        "MACROPROPS": {"ROWS": NARROW["H"], "COLS": NARROW["W"]},
+        "DATASET": {"PAST_LEN": NARROW["P"], "FUTURE_LEN": NARROW["F"], "BATCH_SIZE": B},
+        "MODEL": {"DDPM": {"TIMESTEPS": 1000, "SCALE": 0.5, "UNET": {
+            "CONDITION": "Past", "NUM_RES_BLOCKS": 1, "BASE_CH": 8, "BASE_CH_MULT": [1, 2, 4],
+            "APPLY_ATTENTION": [False, False, True, False], "DROPOUT_RATE": 0.1, "TIME_EMB_MULT": 4}}}})
+    m = DDPM_model(cfg, "DDPM-UNet", C_)
+    ucfg = narrow_cfg(C_)
+    m.denoiser.load_state_dict(spec.init_params(ucfg, SEED_W))
+    past, fut = synth_inputs(B, C_, NARROW["H"], NARROW["W"], NARROW["P"], NARROW["F"], "train")
+    eps = prng.normal(7, "train/eps", fut.size).reshape(fut.shape)
+    masks = {}
+    for blk in spec.make_plan(ucfg).res_blocks():
+        u = prng.uniform_pm1(7, f"drop/{blk.prefix}", B * blk.cout).reshape(B, blk.cout)
+        masks[blk.prefix] = ((u * 0.5 + 0.5) >= 0.1).astype(np.float32) / np.float32(0.9)
+    loss, pred = m._train_step(fut, past, DDPM(timesteps=1000, scale=0.5), t=g["t"], noise=eps, drop_masks=masks)
+    assert np.abs(pred - g["pred"]).max() <= TOL
+    assert abs(loss - float(g["loss"])) <= 1e-5 * max(1.0, float(g["loss"]))
+    # masks drawn on the device: keep-probability and scaling are right, values are {0, 1/(1-p)}
+    m.denoiser.train()
+    p2 = m.denoiser.forward_train(fut, g["t"], past, seed=5)
+    p3 = m.denoiser.forward_train(fut, g["t"], past, seed=5)
+    m.denoiser.eval()
+    assert np.array_equal(p2, p3) and not np.array_equal(p2, pred)
