@@ -86,7 +86,7 @@ hipError_t launch_chan_stats(const float *x, int B, int V, int C, int nslice, fl
 //   gn[b][0][c] = rstd_g*gamma_c ; gn[b][1][c] = beta_c - mean_g*rstd_g*gamma_c
 hipError_t launch_gn_finalize(const float *part0, const float *cnt0, int ns0, int C0, const float *part1,
                               const float *cnt1, int ns1, int C1, int V, const float *gamma, const float *beta,
-                              int groups, float eps, float *gn, int B, hipStream_t st);
+                              int groups, float eps, float *gn, float *mr, int B, hipStream_t st);
 // Second pass of a K-split convolution: out = sum_s part[s] (fixed order) + bias + temb + residual,
 // plus the GroupNorm statistics of out per 32-row slot.  part: [S][B][V][C], C <= 256.
 struct CombineArgs {
@@ -107,7 +107,7 @@ hipError_t launch_extract_output(const float *eps_cl, int cs, float *out, int B,
 //   out[row][0..nproj) = Wd @ silu(W2 @ silu(W1 @ table[t_row] + b1) + b2) + bd
 hipError_t launch_time_mlp(const float *table, const float *W1, const float *b1, const float *W2, const float *b2,
                            const float *Wd, const float *bd, int te, int tx, int nproj, int nrows, float *temb_raw,
-                           float *out, hipStream_t st);
+                           float *out, const long long *rowidx, hipStream_t st);
 // softmax(q k^T / sqrt(d)) v per (sample, head); qkv channels-last [B][S][3E]
 hipError_t launch_attn_core(const float *qkv, float *out, int B, int S, int E, int heads, hipStream_t st);
 
@@ -139,5 +139,49 @@ hipError_t launch_randn(float *x, int B, long long per, unsigned long long seed,
                         hipStream_t st);
 // generic strided copy channels-last -> reference layout (debug hook)
 hipError_t launch_cl_to_ref(const float *x_cl, int cs, float *out, int B, int C, int Z, int Y, int X, hipStream_t st);
+
+// ---- backward pass (cm_train.hip) -----------------------------------------------------
+hipError_t launch_wgrad(const ConvArgs &a, int MB, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb,
+                        hipStream_t st);
+hipError_t launch_wgrad_reduce(const float *part, int G, int ncb, int nkb, int ntaps, int Co, int Ci, float *dW,
+                               hipStream_t st);
+hipError_t launch_voxel_sum(const float *x, int B, int V, int C, int cs, float *out, int ostride, hipStream_t st);
+hipError_t launch_batch_sum(const float *in, int B, int C, int stride, float *out, int accumulate, hipStream_t st);
+struct GnbArgs {
+  const float *x0; const float *x1; int C0, C1;  // forward inputs (channels-last)
+  const float *dA; int dA_cs;                    // gradient w.r.t. the activated tensor, [B][V][>=Ctot]
+  const float *gn;                               // [B][2][Ctot] scale, shift of the forward
+  const float *mr;                               // [B][2][Ctot] mean_g, rstd_g expanded per channel
+  const float *gamma;
+  const float *pm; int pm_stride;
+  int silu;
+  int V, B, groups;
+  float *part;                                   // [B][nsl][Ctot][2]  (sum dy, sum dy*xh)
+  int nsl;
+  float *coef;                                   // [B][3][Ctot]  A_c = rstd*gamma, Bg = rstd*S1/N, Cg = rstd*S2/N
+  float *dgb;                                    // [B][2][Ctot]  per-sample dgamma, dbeta
+  float *g0; float *g1; int acc0, acc1;          // outputs: gradients of x0 / x1 (accumulate flags)
+};
+hipError_t launch_gn_backward(const GnbArgs &a, hipStream_t st);
+hipError_t launch_add_into(float *dst, int dcs, const float *src, int scs, int C, long long rows, int accumulate,
+                           hipStream_t st);
+hipError_t launch_upsample2(const float *x, float *y, int B, int Z, int Y, int X, int C, hipStream_t st);
+hipError_t launch_sumpool2(const float *y, float *x, int B, int Z, int Y, int X, int C, int accumulate, hipStream_t st);
+hipError_t launch_zero_stuff2(const float *y, float *u, int B, int Z, int Y, int X, int C, hipStream_t st);
+hipError_t launch_mse_grad(const float *pred, const float *target, float *g, int B, int C, int H, int W, int P, int F,
+                           hipStream_t st);
+hipError_t launch_attn_bwd(const float *qkv, const float *dO, float *dqkv, int B, int S, int E, int heads, hipStream_t st);
+struct TimeBwdArgs {
+  const float *table; const long long *t;
+  const float *W1, *b1, *W2, *b2, *Wd, *bd;
+  int te, tx, nproj, B;
+  const float *dproj;     // [B][nproj]
+  float *ws;              // workspace: e[B][te], h1[B][tx], z1[B][tx], tev[B][tx], s[B][tx], dte[B][tx], dz1[B][tx]
+  float *dW1, *db1, *dW2, *db2, *dWd, *dbd;
+};
+hipError_t launch_time_bwd(const TimeBwdArgs &a, hipStream_t st);
+hipError_t launch_adam(float *p, const float *g, float *m, float *v, long long n, float lr, float b1, float b2,
+                       float eps, float wd, int step, hipStream_t st);
+hipError_t launch_gather_pack(const float *W, const int *idx, int nk, float *packed, long long n, hipStream_t st);
 
 }  // namespace cm

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
                                                           const float *__restrict__ n1, int ns1, int C1, int V,
                                                           const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, int groups, float eps,
-                                                          float *__restrict__ gn) {
+                                                          float *__restrict__ gn, float *__restrict__ mr) {
   // sm: [nl][Ct][3] partial triples, then [Ct] mean, [Ct] m2, [groups] gmean, [groups] grstd
   extern __shared__ float sm[];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -148,18 +148,22 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
     const float sc = grstd[g] * gamma[c];
     gn[((size_t)b * 2 + 0) * Ct + c] = sc;
     gn[((size_t)b * 2 + 1) * Ct + c] = beta[c] - gmean[g] * sc;
+    if (mr) {  // kept for the backward pass: group mean / rstd expanded per channel
+      mr[((size_t)b * 2 + 0) * Ct + c] = gmean[g];
+      mr[((size_t)b * 2 + 1) * Ct + c] = grstd[g];
+    }
   }
 }
 
 hipError_t launch_gn_finalize(const float *part0, const float *cnt0, int ns0, int C0, const float *part1,
                               const float *cnt1, int ns1, int C1, int V, const float *gamma, const float *beta,
-                              int groups, float eps, float *gn, int B, hipStream_t st) {
+                              int groups, float eps, float *gn, float *mr, int B, hipStream_t st) {
   const int Ct = C0 + C1;
   if (Ct % groups != 0) return hipErrorInvalidValue;
   const int nl = 256 / Ct > 0 ? 256 / Ct : 1;
   const size_t smem = ((size_t)nl * Ct * 3 + 2 * Ct + 2 * groups) * sizeof(float);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), smem, st, part0, cnt0, ns0, C0, part1, cnt1, ns1, C1, V,
-                     gamma, beta, groups, eps, gn);
+                     gamma, beta, groups, eps, gn, mr);
   return hipGetLastError();
 }
 
@@ -329,11 +333,13 @@ __global__ __launch_bounds__(256) void time_mlp_kernel(const float *__restrict__
                                                        const float *__restrict__ b1, const float *__restrict__ W2,
                                                        const float *__restrict__ b2, const float *__restrict__ Wd,
                                                        const float *__restrict__ bd, int te, int tx, int nproj,
-                                                       float *__restrict__ temb_raw, float *__restrict__ out) {
+                                                       float *__restrict__ temb_raw, float *__restrict__ out,
+                                                       const long long *__restrict__ rowidx) {
   extern __shared__ float sm[];  // e[te], h1[tx], h2[tx]
   float *e = sm, *h1 = sm + te, *h2 = h1 + tx;
   const int row = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < te; i += 256) e[i] = table[(size_t)row * te + i];
+  const long long trow = rowidx ? rowidx[row] : row;   // training: table row = t[b]
+  for (int i = tid; i < te; i += 256) e[i] = table[(size_t)trow * te + i];
   __syncthreads();
   for (int o = tid; o < tx; o += 256) {
     float acc = b1[o];
@@ -357,10 +363,10 @@ __global__ __launch_bounds__(256) void time_mlp_kernel(const float *__restrict__
 
 hipError_t launch_time_mlp(const float *table, const float *W1, const float *b1, const float *W2, const float *b2,
                            const float *Wd, const float *bd, int te, int tx, int nproj, int nrows, float *temb_raw,
-                           float *out, hipStream_t st) {
+                           float *out, const long long *rowidx, hipStream_t st) {
   const size_t smem = (size_t)(te + 2 * tx) * sizeof(float);
   hipLaunchKernelGGL(time_mlp_kernel, dim3(nrows), dim3(256), smem, st, table, W1, b1, W2, b2, Wd, bd, te, tx, nproj,
-                     temb_raw, out);
+                     temb_raw, out, rowidx);
   return hipGetLastError();
 }
 

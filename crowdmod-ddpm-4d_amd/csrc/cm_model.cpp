@@ -64,6 +64,8 @@ struct Param {
 struct Act {
   std::string name;
   float *d = nullptr;
+  float *g = nullptr;     // gradient buffer (training)
+  bool gset = false;      // has received a contribution in the current backward pass
   int C = 0, Z = 0, Y = 0, X = 0;
   float *part = nullptr;  // [B][nslots][C][2] per-slot (mean, M2) of every channel
   float *cnt = nullptr;   // [B][nslots] rows behind each slot
@@ -90,6 +92,11 @@ struct Op {
   int *d_hvtab = nullptr, *d_mtab = nullptr;  // device copies of the box coordinate tables
   Act *stat_act = nullptr;  // output tensor whose GroupNorm statistics this conv produces in its epilogue
   int pm_off = -1;          // >= 0: conv_2 of a ResnetBlock; offset of its Dropout3d mask row slice (training forward)
+  const Act *in0 = nullptr, *in1 = nullptr;  // forward inputs (for the backward pass)
+  std::string wname, bname;
+  int temb_off = -1;        // >= 0: slice of the time-embedding projection added in the epilogue
+  int gn_op = -1;           // index of the OP_GNFIN op that produced this conv's on-load normalisation
+  int ref_taps = 1;         // taps of the reference weight (27 even when the forward runs the 8-tap parity form)
   int ks = 1;               // K split over workgroups (tiny-spatial layers) + combine pass
   float *d_zero_bias = nullptr;
   const Act *out_act = nullptr, *resid_act = nullptr;
@@ -106,6 +113,8 @@ struct Op {
   const Act *g0 = nullptr, *g1 = nullptr;
   const float *gamma = nullptr, *beta = nullptr;
   float *gn_out = nullptr;
+  float *gn_mr = nullptr;   // [B][2][Ct] group mean / rstd per channel (allocated when training)
+  std::string gname, bename;  // state_dict names of gamma / beta
   // attention
   const float *qkv = nullptr;
   float *aout = nullptr;
@@ -121,6 +130,7 @@ struct cm_schedule {
   float *d_sab = nullptr, *d_s1m = nullptr;
 };
 
+struct cm_train_state;
 struct cm_model {
   cm_unet_config cfg{};
   int device = 0;
@@ -146,8 +156,14 @@ struct cm_model {
   long long *tbuf = nullptr;    // [B] timestep per sample
   float *temb_table = nullptr;  // [1000][nproj]
   int nproj = 0;
+  float *d_time[7] = {nullptr};  // device copies: table, W1, b1, W2, b2, Wd_all, bd_all
+  struct cm_train_state *train = nullptr;
   float *dropmask = nullptr;    // [B][nproj] Dropout3d keep-mask/(1-p) of the current training forward
   bool train_fwd = false;
+  // training step: time-embedding projections of the batch computed from the live weights
+  float *train_temb = nullptr;  // [B][nproj], row b
+  long long *train_iota = nullptr;
+  bool use_train_temb = false;
   float *mse_partial = nullptr, *mse_loss = nullptr;
   float *ks_scratch = nullptr;  // raw partial outputs of K-split convs [S][B][V][Co]
   size_t ks_scratch_floats = 0;
@@ -551,6 +567,13 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   op.out_act = s.out;
   op.resid_act = s.resid;
   op.pm_off = s.pm_off;
+  op.in0 = s.s0; op.in1 = s.s1;
+  op.wname = s.wname; op.bname = s.bname;
+  op.ref_taps = s.ntaps;
+  op.temb_off = s.temb ? (int)(s.temb - m->temb_table) : -1;
+  if (s.gn)
+    for (int i = (int)m->ops.size() - 1; i >= 0; --i)
+      if (m->ops[i].kind == OP_GNFIN && m->ops[i].gn_out == s.gn) { op.gn_op = i; break; }
   // Tiny-spatial layers (one 54-voxel tile per sample at quarter resolution): the only way to
   // more parallelism AND less weight traffic per workgroup is to split K over workgroups;
   // a second pass sums the partials in a fixed order and applies the epilogue.
@@ -579,6 +602,7 @@ void add_stats(cm_model *m, const Act *a) {
 int add_gnfin(cm_model *m, const Act *g0, const Act *g1, const std::string &wname, const std::string &bname, float **gn_out) {
   Op op;
   op.kind = OP_GNFIN; op.cls = K_NORM; op.g0 = g0; op.g1 = g1; op.label = "gn_finalize(" + wname + ")";
+  op.gname = wname; op.bename = bname;
   float *dg = nullptr, *db = nullptr;
   if (upload(m, P(m, wname).host, &dg)) return 1;
   if (upload(m, P(m, bname).host, &db)) return 1;
@@ -772,7 +796,9 @@ int build_time_table(cm_model *m) {
   if (upload(m, P(m, "time_embeddings.time_blocks.3.bias").host, &db2)) return 1;
   if (upload(m, Wd, &dWd)) return 1;
   if (upload(m, bd, &dbd)) return 1;
-  CM_HIP(cm::launch_time_mlp(dT, dW1, db1, dW2, db2, dWd, dbd, te, tx, m->nproj, TIME_ROWS, nullptr, m->temb_table, m->stream));
+  m->d_time[0] = dT; m->d_time[1] = dW1; m->d_time[2] = db1; m->d_time[3] = dW2; m->d_time[4] = db2;
+  m->d_time[5] = dWd; m->d_time[6] = dbd;
+  CM_HIP(cm::launch_time_mlp(dT, dW1, db1, dW2, db2, dWd, dbd, te, tx, m->nproj, TIME_ROWS, nullptr, m->temb_table, nullptr, m->stream));
   CM_HIP(hipStreamSynchronize(m->stream));
   return 0;
 }
@@ -822,6 +848,10 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
         if (m->train_fwd && op.pm_off >= 0) {
           ca.pm = m->dropmask + (size_t)b0 * m->nproj + op.pm_off;
           ca.pm_stride = m->nproj;
+        }
+        if (m->use_train_temb && op.temb_off >= 0) {
+          ca.temb = m->train_temb + op.temb_off;
+          ca.tidx = m->train_iota + b0;
         }
         if (ca.resid) ca.resid += (size_t)b0 * Vo * ca.res_cs;
         ca.out += (size_t)b0 * Vo * ca.out_cs;
@@ -877,7 +907,7 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
                                       g0->nslots, g0->C, g1 ? g1->part + (size_t)b0 * g1->nslots * g1->C * 2 : nullptr,
                                       g1 ? g1->cnt + (size_t)b0 * g1->nslots : nullptr, g1 ? g1->nslots : 0,
                                       g1 ? g1->C : 0, g0->V(), op.gamma, op.beta, GN_GROUPS, GN_EPS,
-                                      op.gn_out + (size_t)b0 * 2 * Ct, B, st));
+                                      op.gn_out + (size_t)b0 * 2 * Ct, op.gn_mr ? op.gn_mr + (size_t)b0 * 2 * Ct : nullptr, B, st));
         break;
       }
       case OP_ATTN:
@@ -1492,3 +1522,5 @@ int cm_model_class_flops(const cm_model *m, int32_t B, double flops[8]) {
 }
 
 }  // extern "C"
+
+#include "cm_train_host.inc"

@@ -1,0 +1,685 @@
+// Backward-pass kernels of the DDPM-UNet training step
+// (/root/reference/models/diffusion/ddpm.py:111-121,142-144: loss.backward() + Adam).
+// Correctness-first round: every reduction has a fixed order (no atomics), the heavy
+// contraction (weight gradient) runs on the fp32 matrix cores, the rest are small
+// HBM/latency-bound kernels.  Data gradients of the convolutions reuse the forward
+// implicit-GEMM kernel (cm_conv.hip) with transposed / flipped packed weights.
+#include "cm_kernels.h"
+
+namespace cm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// --------------------------------------------------------------------------------
+// Weight gradient of a convolution:  dW[tap][co][ci] = sum_{b,v} dy[b,v,co] * a[b, v*stride+tap-pad, ci]
+// where a = pm * silu(gn(x)) is the conv's ACTUAL input, recomputed on the fly from the raw
+// producer tensor exactly as the forward staging does (it was never materialised).
+// One workgroup owns a (32-co block, 32-ci block) pair and a strided subset of the voxel
+// tiles; per tile it stages the dy rows and the input halo into LDS, and its 4 waves split
+// the taps.  MFMA 32x32x2 with the VOXEL index as the contraction dimension:
+//   A operand = dy[m][co] (lane: co = l&31, k = l>>5),  B operand = a[m+tap][ci].
+// Partials go to part[g][cb][kb][tap][32][32]; wgrad_reduce sums them in order.
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const float *__restrict__ dy, int dy_cs,
+                                                    float *__restrict__ part, int G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int g = blockIdx.x, cb = blockIdx.y, kb = blockIdx.z;
+  const int td = a.td, pad = (td == 3) ? 1 : 0;
+  const int HZ = (a.bz - 1) * a.stride + td, HY = (a.by - 1) * a.stride + td, HX = (a.bx - 1) * a.stride + td;
+  const int HV = HZ * HY * HX;
+  const int nbox = a.bz * a.by * a.bx;
+  const int TM = (nbox + 31) & ~31;
+  const int ntile = a.nts * a.ntz * a.nty * a.ntx;
+  const int Ctot = a.C0 + a.C1;
+
+  int *rowhv = reinterpret_cast<int *>(lds);  // [TM] halo index of each output row (box-relative)
+  int *rowoff = rowhv + TM;                   // [TM] output voxel index of the row in the current tile, or -1
+  float *dyt = lds + 2 * TM;                  // [TM][32]
+  float *at = dyt + TM * 32;                  // [HV][32]
+
+  for (int m = tid; m < TM; m += 256) {
+    int hv = 0;
+    const int pk = m < nbox ? a.mtab[m] : -1;
+    if (pk >= 0) hv = ((((pk >> 18) & 255) * a.stride) * HY + ((pk >> 9) & 511) * a.stride) * HX + (pk & 511) * a.stride;
+    rowhv[m] = hv;
+  }
+  // input channels of this block in the concatenated channel space (a 4-channel group never
+  // straddles the concat boundary: C0 is a multiple of 8)
+  const int ci0 = kb * 32;
+  const int ntaps = a.ntaps;
+  constexpr int TW = 7;                       // taps per wave (27 = 7+7+7+6)
+  f32x16 acc[TW];
+#pragma unroll
+  for (int i = 0; i < TW; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  const int Zc = a.Zs << a.ups, Yc = a.Ys << a.ups, Xc = a.Xs << a.ups;
+  for (int tile = g; tile < ntile; tile += G) {
+    int tt = tile;
+    const int tx = tt % a.ntx; tt /= a.ntx;
+    const int ty = tt % a.nty; tt /= a.nty;
+    const int tz = tt % a.ntz;
+    const int b = tt / a.ntz;
+    const int z0 = tz * a.bz, y0 = ty * a.by, x0 = tx * a.bx;
+    __syncthreads();
+    // rows of this tile
+    for (int m = tid; m < TM; m += 256) {
+      int off = -1;
+      const int pk = m < nbox ? a.mtab[m] : -1;
+      if (pk >= 0) {
+        const int oz = z0 + ((pk >> 18) & 255), oy = y0 + ((pk >> 9) & 511), ox = x0 + (pk & 511);
+        if (oz < a.Zo && oy < a.Yo && ox < a.Xo) off = ((b * a.Zo + oz) * a.Yo + oy) * a.Xo + ox;
+      }
+      rowoff[m] = off;
+    }
+    __syncthreads();
+    // dy tile
+    for (int i = tid; i < TM * 8; i += 256) {
+      const int m = i >> 3, q = i & 7;
+      const int off = rowoff[m];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (off >= 0) {
+        const int co = cb * 32 + 4 * q;
+        const float *p = dy + (size_t)off * dy_cs + co;
+        v[0] = co + 0 < a.Co ? p[0] : 0.f; v[1] = co + 1 < a.Co ? p[1] : 0.f;
+        v[2] = co + 2 < a.Co ? p[2] : 0.f; v[3] = co + 3 < a.Co ? p[3] : 0.f;
+      }
+      *reinterpret_cast<f32x4 *>(&dyt[m * 32 + 4 * q]) = v;
+    }
+    // input halo (same transform as the forward staging)
+    const int cz0 = z0 * a.stride - pad, cy0 = y0 * a.stride - pad, cx0 = x0 * a.stride - pad;
+    for (int i = tid; i < HV * 8; i += 256) {
+      const int hv = i >> 3, q = i & 7;
+      const int pk = a.hvtab[hv];
+      const int cx = cx0 + (pk & 511), cy = cy0 + ((pk >> 9) & 511), cz = cz0 + ((pk >> 18) & 255);
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      const int c = ci0 + 4 * q;
+      if (c < Ctot && cz >= 0 && cz < Zc && cy >= 0 && cy < Yc && cx >= 0 && cx < Xc) {
+        const int off = ((b * a.Zs + (cz >> a.ups)) * a.Ys + (cy >> a.ups)) * a.Xs + (cx >> a.ups);
+        w = (c < a.C0) ? *reinterpret_cast<const f32x4 *>(a.src0 + (size_t)off * a.C0 + c)
+                       : *reinterpret_cast<const f32x4 *>(a.src1 + (size_t)off * a.C1 + (c - a.C0));
+        if (a.gn) {
+          const float *gp = a.gn + (size_t)b * 2 * Ctot + ci0 + 4 * q;
+          w = w * *reinterpret_cast<const f32x4 *>(gp) + *reinterpret_cast<const f32x4 *>(gp + Ctot);
+          if (a.silu) { w[0] *= sigmoid_f(w[0]); w[1] *= sigmoid_f(w[1]); w[2] *= sigmoid_f(w[2]); w[3] *= sigmoid_f(w[3]); }
+        }
+        if (a.pm) w = w * *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + ci0 + 4 * q);
+      }
+      *reinterpret_cast<f32x4 *>(&at[hv * 32 + 4 * q]) = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < TW; ++ti) {
+      const int t = wave + 4 * ti;
+      if (t < ntaps) {
+        const int dz = t / (td * td), rem = t - dz * td * td, dyy = rem / td, dx = rem - dyy * td;
+        const int tapoff = (dz * HY + dyy) * HX + dx;
+        for (int m0 = 0; m0 < TM; m0 += 2) {
+          const float av = dyt[(m0 + h) * 32 + r];
+          const float bv = at[(rowhv[m0 + h] + tapoff) * 32 + r];
+          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ti], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ti = 0; ti < TW; ++ti) {
+    const int t = wave + 4 * ti;
+    if (t < ntaps) {
+      float *p = part + ((((size_t)g * gridDim.y + cb) * gridDim.z + kb) * ntaps + t) * 1024;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int co = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        p[co * 32 + r] = acc[ti][reg];
+      }
+    }
+  }
+}
+
+hipError_t launch_wgrad(const ConvArgs &a, int MB, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb,
+                        hipStream_t st) {
+  if (a.bs != 1 || a.par) return hipErrorInvalidValue;
+  const int HV = ((a.bz - 1) * a.stride + a.td) * ((a.by - 1) * a.stride + a.td) * ((a.bx - 1) * a.stride + a.td);
+  const int TM = 32 * MB;
+  const size_t lds = ((size_t)2 * TM + (size_t)TM * 32 + (size_t)HV * 32) * 4;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_set[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set[dev & 63] = true;
+  }
+  hipLaunchKernelGGL(wgrad_kernel, dim3(G, ncb, nkb), dim3(256), lds, st, a, dy, dy_cs, part, G);
+  return hipGetLastError();
+}
+
+// part[g][cb][kb][tap][32 co][32 ci] summed over g (fixed order) -> reference weight layout
+// [Co][Ci][kH][kW][kL] (internal tap (dz,dy,dx) = reference [kH=dy][kW=dx][kL=dz]); 1 tap -> [Co][Ci].
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int G, int ncb, int nkb,
+                                                           int ntaps, int Co, int Ci, float *__restrict__ dW) {
+  const long long total = (long long)Co * Ci * ntaps;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int t = (int)(i % ntaps);
+  long long q = i / ntaps;
+  const int ci = (int)(q % Ci);
+  const int co = (int)(q / Ci);
+  const int cb = co >> 5, kb = ci >> 5;
+  float s = 0.f;
+  for (int g = 0; g < G; ++g)
+    s += part[((((size_t)g * ncb + cb) * nkb + kb) * ntaps + t) * 1024 + (co & 31) * 32 + (ci & 31)];
+  int tref = 0;
+  if (ntaps == 27) { const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3; tref = (dy * 3 + dx) * 3 + dz; }
+  dW[((size_t)co * Ci + ci) * ntaps + tref] = s;
+}
+
+hipError_t launch_wgrad_reduce(const float *part, int G, int ncb, int nkb, int ntaps, int Co, int Ci, float *dW,
+                               hipStream_t st) {
+  const long long total = (long long)Co * Ci * ntaps;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, G, ncb, nkb,
+                     ntaps, Co, Ci, dW);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
+// Per-(sample, channel) sums over the voxels of a channels-last tensor: out[b][c] = sum_v x[b][v][c].
+// Gives the bias gradient (summed over b afterwards) and the gradient of the broadcast
+// time-embedding term h += dense_1(...)[:, :, None, None, None] (layers.py:62).
+// grid B, 256 threads, fixed summation order.
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void voxel_sum_kernel(const float *__restrict__ x, int V, int C, int cs,
+                                                        float *__restrict__ out, int ostride) {
+  __shared__ float sh[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    const int c = c0 + (tid & 31), vl = tid >> 5;  // 8 voxel lanes
+    float s = 0.f;
+    if (c < C)
+      for (int v = vl; v < V; v += 8) s += x[((size_t)b * V + v) * cs + c];
+    sh[tid] = s;
+    __syncthreads();
+    if (tid < 32 && c < C) {
+      float t = 0.f;
+      for (int l = 0; l < 8; ++l) t += sh[l * 32 + tid];
+      out[(size_t)b * ostride + c] = t;
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_voxel_sum(const float *x, int B, int V, int C, int cs, float *out, int ostride, hipStream_t st) {
+  hipLaunchKernelGGL(voxel_sum_kernel, dim3(B), dim3(256), 0, st, x, V, C, cs, out, ostride);
+  return hipGetLastError();
+}
+
+// out[c] (+)= sum_b in[b][c]
+__global__ void batch_sum_kernel(const float *__restrict__ in, int B, int C, int stride, float *__restrict__ out,
+                                 int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += in[(size_t)b * stride + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+hipError_t launch_batch_sum(const float *in, int B, int C, int stride, float *out, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(batch_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, in, B, C, stride, out, accumulate);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
+// GroupNorm (+SiLU, +Dropout3d multiplier) backward, three small kernels.
+//   forward:  xh = (x - mu_g) * rstd_g ;  y = gamma*xh + beta ;  a = pm * silu(y)      (silu optional)
+//   given dA: dy = dA * pm * silu'(y)
+//             dgamma_c = sum_{b,v} dy*xh ; dbeta_c = sum_{b,v} dy
+//             dx = rstd*gamma*dy - (rstd/N) * (S1_g + xh * S2_g),  S1 = sum_g gamma*dy, S2 = sum_g gamma*dy*xh
+// x may be the channel concatenation of two tensors (groups may straddle the boundary).
+// --------------------------------------------------------------------------------
+
+__device__ __forceinline__ float gnb_dy(const GnbArgs &a, int b, int c, int Ctot, float x, float dA, float &xh) {
+  const float mu = a.mr[((size_t)b * 2) * Ctot + c], rstd = a.mr[((size_t)b * 2 + 1) * Ctot + c];
+  xh = (x - mu) * rstd;
+  float d = dA;
+  if (a.pm) d *= a.pm[(size_t)b * a.pm_stride + c];
+  if (a.silu) {
+    const float y = a.gn[((size_t)b * 2) * Ctot + c] * x + a.gn[((size_t)b * 2 + 1) * Ctot + c];
+    const float s = sigmoid_f(y);
+    d *= s * (1.0f + y * (1.0f - s));
+  }
+  return d;
+}
+
+__global__ __launch_bounds__(256) void gnb_reduce_kernel(const GnbArgs a) {
+  __shared__ float sh[512];
+  const int sl = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int Ctot = a.C0 + a.C1;
+  const int vs = (a.V + a.nsl - 1) / a.nsl, v0 = sl * vs, v1 = min(a.V, v0 + vs);
+  for (int cbase = 0; cbase < Ctot; cbase += 32) {
+    const int c = cbase + (tid & 31), vl = tid >> 5;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < Ctot) {
+      const float *xp; int Cx, cc;
+      if (c < a.C0) { xp = a.x0; Cx = a.C0; cc = c; } else { xp = a.x1; Cx = a.C1; cc = c - a.C0; }
+      for (int v = v0 + vl; v < v1; v += 8) {
+        const size_t row = (size_t)b * a.V + v;
+        float xh;
+        const float d = gnb_dy(a, b, c, Ctot, xp[row * Cx + cc], a.dA[row * a.dA_cs + c], xh);
+        s1 += d;
+        s2 += d * xh;
+      }
+    }
+    sh[tid] = s1; sh[256 + tid] = s2;
+    __syncthreads();
+    if (tid < 32 && c < Ctot) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int l = 0; l < 8; ++l) { t1 += sh[l * 32 + tid]; t2 += sh[256 + l * 32 + tid]; }
+      float *p = a.part + (((size_t)b * a.nsl + sl) * Ctot + c) * 2;
+      p[0] = t1; p[1] = t2;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void gnb_finalize_kernel(const GnbArgs a) {
+  extern __shared__ float sm[];  // [Ctot] s1, [Ctot] s2, [groups] S1, [groups] S2
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Ctot = a.C0 + a.C1;
+  float *s1 = sm, *s2 = sm + Ctot, *S1 = sm + 2 * Ctot, *S2 = S1 + a.groups;
+  for (int c = tid; c < Ctot; c += 256) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int s = 0; s < a.nsl; ++s) {
+      const float *p = a.part + (((size_t)b * a.nsl + s) * Ctot + c) * 2;
+      t1 += p[0]; t2 += p[1];
+    }
+    s1[c] = t1; s2[c] = t2;
+    a.dgb[((size_t)b * 2) * Ctot + c] = t2;       // dgamma contribution of this sample
+    a.dgb[((size_t)b * 2 + 1) * Ctot + c] = t1;   // dbeta
+  }
+  __syncthreads();
+  const int cg = Ctot / a.groups;
+  if (tid < a.groups) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int i = 0; i < cg; ++i) { const int c = tid * cg + i; t1 += a.gamma[c] * s1[c]; t2 += a.gamma[c] * s2[c]; }
+    S1[tid] = t1; S2[tid] = t2;
+  }
+  __syncthreads();
+  const float invN = 1.0f / ((float)cg * (float)a.V);
+  for (int c = tid; c < Ctot; c += 256) {
+    const int gidx = c / cg;
+    const float rstd = a.mr[((size_t)b * 2 + 1) * Ctot + c];
+    a.coef[((size_t)b * 3 + 0) * Ctot + c] = rstd * a.gamma[c];
+    a.coef[((size_t)b * 3 + 1) * Ctot + c] = rstd * S1[gidx] * invN;
+    a.coef[((size_t)b * 3 + 2) * Ctot + c] = rstd * S2[gidx] * invN;
+  }
+}
+
+__global__ __launch_bounds__(256) void gnb_apply_kernel(const GnbArgs a) {
+  const int Ctot = a.C0 + a.C1;
+  const long long total = (long long)a.B * a.V * Ctot;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % Ctot);
+  const long long row = i / Ctot;
+  const int b = (int)(row / a.V);
+  const float *xp; float *gp; int Cx, cc, accf;
+  if (c < a.C0) { xp = a.x0; gp = a.g0; Cx = a.C0; cc = c; accf = a.acc0; }
+  else { xp = a.x1; gp = a.g1; Cx = a.C1; cc = c - a.C0; accf = a.acc1; }
+  float xh;
+  const float d = gnb_dy(a, b, c, Ctot, xp[row * Cx + cc], a.dA[row * a.dA_cs + c], xh);
+  const float dx = a.coef[((size_t)b * 3 + 0) * Ctot + c] * d - a.coef[((size_t)b * 3 + 1) * Ctot + c] -
+                   xh * a.coef[((size_t)b * 3 + 2) * Ctot + c];
+  float *o = gp + row * Cx + cc;
+  *o = accf ? *o + dx : dx;
+}
+
+hipError_t launch_gn_backward(const GnbArgs &a, hipStream_t st) {
+  const int Ctot = a.C0 + a.C1;
+  hipLaunchKernelGGL(gnb_reduce_kernel, dim3(a.nsl, a.B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(gnb_finalize_kernel, dim3(a.B), dim3(256), (size_t)(2 * Ctot + 2 * a.groups) * sizeof(float), st, a);
+  const long long total = (long long)a.B * a.V * Ctot;
+  hipLaunchKernelGGL(gnb_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
+// Elementwise helpers of the backward graph
+// --------------------------------------------------------------------------------
+// dst[b][v][c] (+)= src[b][v][c]   (channels-last, possibly different channel strides)
+__global__ void add_into_kernel(float *__restrict__ dst, int dcs, const float *__restrict__ src, int scs, int C,
+                                long long rows, int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * C) return;
+  const int c = (int)(i % C);
+  const long long row = i / C;
+  const float v = src[row * scs + c];
+  float *o = dst + row * dcs + c;
+  *o = accumulate ? *o + v : v;
+}
+
+hipError_t launch_add_into(float *dst, int dcs, const float *src, int scs, int C, long long rows, int accumulate,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(add_into_kernel, dim3((unsigned)((rows * C + 255) / 256)), dim3(256), 0, st, dst, dcs, src, scs,
+                     C, rows, accumulate);
+  return hipGetLastError();
+}
+
+// nearest x2 upsample of a channels-last tensor (materialised only for the weight gradient of
+// the upsample conv) and its adjoint (2x2x2 sum pooling).
+__global__ void upsample2_kernel(const float *__restrict__ x, float *__restrict__ y, int B, int Z, int Y, int X, int C) {
+  const long long total = (long long)B * 8 * Z * Y * X * C;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  long long q = i / C;
+  const int ux = (int)(q % (2 * X)); q /= 2 * X;
+  const int uy = (int)(q % (2 * Y)); q /= 2 * Y;
+  const int uz = (int)(q % (2 * Z));
+  const int b = (int)(q / (2 * Z));
+  y[i] = x[((((size_t)b * Z + (uz >> 1)) * Y + (uy >> 1)) * X + (ux >> 1)) * C + c];
+}
+
+__global__ void sumpool2_kernel(const float *__restrict__ y, float *__restrict__ x, int B, int Z, int Y, int X, int C,
+                                int accumulate) {
+  const long long total = (long long)B * Z * Y * X * C;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  long long q = i / C;
+  const int xx = (int)(q % X); q /= X;
+  const int yy = (int)(q % Y); q /= Y;
+  const int zz = (int)(q % Z);
+  const int b = (int)(q / Z);
+  float s = 0.f;
+  for (int dz = 0; dz < 2; ++dz)
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dx = 0; dx < 2; ++dx)
+        s += y[((((size_t)b * 2 * Z + 2 * zz + dz) * 2 * Y + 2 * yy + dy) * 2 * X + 2 * xx + dx) * C + c];
+  x[i] = accumulate ? x[i] + s : s;
+}
+
+hipError_t launch_upsample2(const float *x, float *y, int B, int Z, int Y, int X, int C, hipStream_t st) {
+  const long long total = (long long)B * 8 * Z * Y * X * C;
+  hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, y, B, Z, Y, X, C);
+  return hipGetLastError();
+}
+
+hipError_t launch_sumpool2(const float *y, float *x, int B, int Z, int Y, int X, int C, int accumulate, hipStream_t st) {
+  const long long total = (long long)B * Z * Y * X * C;
+  hipLaunchKernelGGL(sumpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, y, x, B, Z, Y, X, C,
+                     accumulate);
+  return hipGetLastError();
+}
+
+// Adjoint of "take every second voxel" used by the stride-2 conv data gradient: y (Z,Y,X) is
+// written into the even positions of a zero tensor of size (2Z,2Y,2X).
+__global__ void zero_stuff2_kernel(const float *__restrict__ y, float *__restrict__ u, int B, int Z, int Y, int X, int C) {
+  const long long total = (long long)B * 8 * Z * Y * X * C;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  long long q = i / C;
+  const int ux = (int)(q % (2 * X)); q /= 2 * X;
+  const int uy = (int)(q % (2 * Y)); q /= 2 * Y;
+  const int uz = (int)(q % (2 * Z));
+  const int b = (int)(q / (2 * Z));
+  float v = 0.f;
+  if (!((ux | uy | uz) & 1)) v = y[((((size_t)b * Z + (uz >> 1)) * Y + (uy >> 1)) * X + (ux >> 1)) * C + c];
+  u[i] = v;
+}
+
+hipError_t launch_zero_stuff2(const float *y, float *u, int B, int Z, int Y, int X, int C, hipStream_t st) {
+  const long long total = (long long)B * 8 * Z * Y * X * C;
+  hipLaunchKernelGGL(zero_stuff2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, y, u, B, Z, Y, X, C);
+  return hipGetLastError();
+}
+
+// d(loss)/d(eps_hat) of mean((eps_hat - eps)^2) written into the channels-last gradient of the
+// final conv output [B][L][H][W][8]: zero for the past frames (unet.py:166 slices them away)
+// and for the padding channels.
+__global__ void mse_grad_kernel(const float *__restrict__ pred, const float *__restrict__ target,
+                                float *__restrict__ g, int B, int C, int H, int W, int P, int F) {
+  const int L = P + F;
+  const long long total = (long long)B * L * H * W * 8;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i & 7);
+  long long q = i >> 3;
+  const int w = (int)(q % W); q /= W;
+  const int hh = (int)(q % H); q /= H;
+  const int l = (int)(q % L);
+  const int b = (int)(q / L);
+  float v = 0.f;
+  if (c < C && l >= P) {
+    const size_t ref = ((((size_t)b * C + c) * H + hh) * W + w) * F + (l - P);
+    v = 2.0f * (pred[ref] - target[ref]) / (float)((long long)B * C * H * W * F);
+  }
+  g[i] = v;
+}
+
+hipError_t launch_mse_grad(const float *pred, const float *target, float *g, int B, int C, int H, int W, int P, int F,
+                           hipStream_t st) {
+  const long long total = (long long)B * (P + F) * H * W * 8;
+  hipLaunchKernelGGL(mse_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pred, target, g, B, C,
+                     H, W, P, F);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
+// Attention core backward per (sample, head): P = softmax(q k^T * s);  O = P v
+//   dV = P^T dO ; dP = dO V^T ; dS = P o (dP - rowsum(dP o P)) ; dQ = s * dS K ; dK = s * dS^T Q
+// qkv / dqkv channels-last [B][S][3E]; dO [B][S][E].  S <= 256 (rows handled by threads).
+// --------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ dO,
+                                                       float *__restrict__ dqkv, int S, int E) {
+  extern __shared__ float sm[];  // Q[S][D] K[S][D] V[S][D] dO[S][D] P[S][S] dS[S][S]
+  float *Q = sm, *K = Q + S * D, *Vv = K + S * D, *dOs = Vv + S * D, *Pm = dOs + S * D, *dSm = Pm + S * S;
+  const int hd = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float *base = qkv + (size_t)b * S * 3 * E;
+  for (int i = tid; i < S * D; i += 256) {
+    const int s = i / D, d = i % D;
+    Q[i] = base[(size_t)s * 3 * E + hd * D + d];
+    K[i] = base[(size_t)s * 3 * E + E + hd * D + d];
+    Vv[i] = base[(size_t)s * 3 * E + 2 * E + hd * D + d];
+    dOs[i] = dO[((size_t)b * S + s) * E + hd * D + d];
+  }
+  __syncthreads();
+  const float scale = rsqrtf((float)D);
+  for (int row = tid; row < S; row += 256) {
+    float mx = -3.0e38f;
+    for (int j = 0; j < S; ++j) {
+      float sc = 0.f;
+      for (int d = 0; d < D; ++d) sc = fmaf(Q[row * D + d], K[j * D + d], sc);
+      sc *= scale;
+      Pm[row * S + j] = sc;
+      mx = fmaxf(mx, sc);
+    }
+    float l = 0.f;
+    for (int j = 0; j < S; ++j) { const float p = __expf(Pm[row * S + j] - mx); Pm[row * S + j] = p; l += p; }
+    const float inv = 1.0f / l;
+    float dot = 0.f;
+    for (int j = 0; j < S; ++j) {
+      const float p = Pm[row * S + j] * inv;
+      Pm[row * S + j] = p;
+      float dp = 0.f;
+      for (int d = 0; d < D; ++d) dp = fmaf(dOs[row * D + d], Vv[j * D + d], dp);
+      dSm[row * S + j] = dp;
+      dot = fmaf(dp, p, dot);
+    }
+    for (int j = 0; j < S; ++j) dSm[row * S + j] = Pm[row * S + j] * (dSm[row * S + j] - dot);
+  }
+  __syncthreads();
+  float *ob = dqkv + (size_t)b * S * 3 * E;
+  for (int i = tid; i < S * D; i += 256) {
+    const int s = i / D, d = i % D;
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int j = 0; j < S; ++j) {
+      dq = fmaf(dSm[s * S + j], K[j * D + d], dq);
+      dk = fmaf(dSm[j * S + s], Q[j * D + d], dk);
+      dv = fmaf(Pm[j * S + s], dOs[j * D + d], dv);
+    }
+    ob[(size_t)s * 3 * E + hd * D + d] = dq * scale;
+    ob[(size_t)s * 3 * E + E + hd * D + d] = dk * scale;
+    ob[(size_t)s * 3 * E + 2 * E + hd * D + d] = dv;
+  }
+}
+
+hipError_t launch_attn_bwd(const float *qkv, const float *dO, float *dqkv, int B, int S, int E, int heads, hipStream_t st) {
+  const int D = E / heads;
+  const size_t smem = ((size_t)4 * S * D + (size_t)2 * S * S) * sizeof(float);
+  if (smem > 160 * 1024) return hipErrorInvalidValue;
+#define CM_AB(DD)                                                                                         \
+  if (D == DD) {                                                                                          \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_kernel<DD>),               \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
+    if (e != hipSuccess) return e;                                                                        \
+    hipLaunchKernelGGL((attn_bwd_kernel<DD>), dim3(heads, B), dim3(256), smem, st, qkv, dO, dqkv, S, E);    \
+    return hipGetLastError();                                                                             \
+  }
+  CM_AB(8) CM_AB(16) CM_AB(32) CM_AB(64)
+#undef CM_AB
+  return hipErrorInvalidValue;
+}
+
+// --------------------------------------------------------------------------------
+// Time-embedding path, forward for the B timesteps of a training batch and backward.
+//   e = table[t] ; z1 = W1 e + b1 ; h1 = silu(z1) ; te = W2 h1 + b2 ; s = silu(te) ; proj = Wd s + bd
+// One workgroup; B <= 256.  The forward writes proj rows [B][nproj] (the conv epilogues then
+// index row b); the backward consumes dproj [B][nproj] and produces all weight gradients.
+// --------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void time_bwd_kernel(const TimeBwdArgs a) {
+  const int tid = threadIdx.x;
+  const int B = a.B, te = a.te, tx = a.tx, np = a.nproj;
+  float *e = a.ws, *h1 = e + (size_t)B * te, *z1 = h1 + (size_t)B * tx, *tev = z1 + (size_t)B * tx,
+        *sv = tev + (size_t)B * tx, *dte = sv + (size_t)B * tx, *dz1 = dte + (size_t)B * tx;
+  for (int i = tid; i < B * te; i += 256) e[i] = a.table[(size_t)a.t[i / te] * te + i % te];
+  __syncthreads();
+  for (int i = tid; i < B * tx; i += 256) {
+    const int b = i / tx, o = i % tx;
+    float acc = a.b1[o];
+    for (int k = 0; k < te; ++k) acc = fmaf(a.W1[(size_t)o * te + k], e[b * te + k], acc);
+    z1[i] = acc;
+    h1[i] = acc * sigmoid_f(acc);
+  }
+  __syncthreads();
+  for (int i = tid; i < B * tx; i += 256) {
+    const int b = i / tx, o = i % tx;
+    float acc = a.b2[o];
+    for (int k = 0; k < tx; ++k) acc = fmaf(a.W2[(size_t)o * tx + k], h1[b * tx + k], acc);
+    tev[i] = acc;
+    sv[i] = acc * sigmoid_f(acc);
+  }
+  __syncthreads();
+  // dWd[o][k] = sum_b dproj[b][o] * s[b][k] ; dbd[o] = sum_b dproj[b][o]
+  for (int i = tid; i < np * tx; i += 256) {
+    const int o = i / tx, k = i % tx;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc = fmaf(a.dproj[(size_t)b * np + o], sv[b * tx + k], acc);
+    a.dWd[i] = acc;
+  }
+  for (int o = tid; o < np; o += 256) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += a.dproj[(size_t)b * np + o];
+    a.dbd[o] = acc;
+  }
+  // dte[b][k] = (sum_o dproj[b][o] Wd[o][k]) * silu'(te)
+  for (int i = tid; i < B * tx; i += 256) {
+    const int b = i / tx, k = i % tx;
+    float acc = 0.f;
+    for (int o = 0; o < np; ++o) acc = fmaf(a.dproj[(size_t)b * np + o], a.Wd[(size_t)o * tx + k], acc);
+    const float y = tev[i], s = sigmoid_f(y);
+    dte[i] = acc * s * (1.0f + y * (1.0f - s));
+  }
+  __syncthreads();
+  for (int i = tid; i < tx * tx; i += 256) {
+    const int o = i / tx, k = i % tx;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc = fmaf(dte[b * tx + o], h1[b * tx + k], acc);
+    a.dW2[i] = acc;
+  }
+  for (int o = tid; o < tx; o += 256) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += dte[b * tx + o];
+    a.db2[o] = acc;
+  }
+  for (int i = tid; i < B * tx; i += 256) {
+    const int b = i / tx, k = i % tx;
+    float acc = 0.f;
+    for (int o = 0; o < tx; ++o) acc = fmaf(dte[b * tx + o], a.W2[(size_t)o * tx + k], acc);
+    const float y = z1[i], s = sigmoid_f(y);
+    dz1[i] = acc * s * (1.0f + y * (1.0f - s));
+  }
+  __syncthreads();
+  for (int i = tid; i < tx * te; i += 256) {
+    const int o = i / te, k = i % te;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc = fmaf(dz1[b * tx + o], e[b * te + k], acc);
+    a.dW1[i] = acc;
+  }
+  for (int o = tid; o < tx; o += 256) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += dz1[b * tx + o];
+    a.db1[o] = acc;
+  }
+}
+
+hipError_t launch_time_bwd(const TimeBwdArgs &a, hipStream_t st) {
+  hipLaunchKernelGGL(time_bwd_kernel, dim3(1), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
+// Adam with coupled L2 (torch.optim.Adam(weight_decay=wd), ddpm.py:53-56), elementwise.
+// --------------------------------------------------------------------------------
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                            float *__restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float bc2) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gg = g[i] + wd * p[i];
+  const float mm = b1 * m[i] + (1.0f - b1) * gg;
+  const float vv = b2 * v[i] + (1.0f - b2) * gg * gg;
+  m[i] = mm;
+  v[i] = vv;
+  p[i] -= (lr / bc1) * mm / (sqrtf(vv) / sqrtf(bc2) + eps);
+}
+
+hipError_t launch_adam(float *p, const float *g, float *m, float *v, long long n, float lr, float b1, float b2,
+                       float eps, float wd, int step, hipStream_t st) {
+  const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps,
+                     wd, bc1, bc2);
+  return hipGetLastError();
+}
+
+// packed[i] = sum_{k<8} W[idx[i][k]]  (idx < 0: skipped) -- re-packs a master weight tensor into
+// an MFMA fragment layout (forward, data-gradient or parity layout) after an optimizer step.
+__global__ void gather_pack_kernel(const float *__restrict__ W, const int *__restrict__ idx, int nk,
+                                   float *__restrict__ packed, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nk; ++k) {
+    const int j = idx[i * nk + k];
+    if (j >= 0) s += W[j];
+  }
+  packed[i] = s;
+}
+
+hipError_t launch_gather_pack(const float *W, const int *idx, int nk, float *packed, long long n, hipStream_t st) {
+  hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, idx, nk, packed, n);
+  return hipGetLastError();
+}
+
+}  // namespace cm

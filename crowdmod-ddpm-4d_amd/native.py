@@ -85,6 +85,11 @@ SIGNATURES = {
     "cm_profile_report": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "cm_model_cost": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cm_model_class_flops": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double)]),
+    "cm_train_init": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "cm_train_set_lr": (C.c_int, [_P, C.c_float]),
+    "cm_train_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_float), C.c_int32, C.c_int32, _P]),
+    "cm_train_get_grad": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "cm_train_sync": (C.c_int, [_P]),
 }
 
 

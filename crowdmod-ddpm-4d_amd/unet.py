@@ -92,6 +92,7 @@ class UNet:
             native.lib().cm_model_destroy(self._handle)
             self._handle = None
             self._geom = None
+            self._train_ready = False
 
     def __del__(self):
         try:
@@ -203,6 +204,67 @@ class UNet:
                                              int(sample_id_base), dout.ptr, B, None))
         native.check(L.cm_device_synchronize(dev))
         return dout.download(fut.shape)
+
+    # -- training step (ddpm.py:111-121,142-144) -------------------------------------
+    def train_init(self, lr=5e-5, betas=(0.5, 0.999), eps=1e-8, weight_decay=0.003):
+        """Device-side optimizer state: torch.optim.Adam(lr, betas, weight_decay) of ddpm.py:53-56."""
+        if self._handle is None:
+            raise RuntimeError("call ensure() (or run a forward) before train_init()")
+        native.check(native.lib().cm_train_init(self._handle, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                                float(weight_decay)))
+        self._train_ready = True
+
+    def set_lr(self, lr: float):
+        native.check(native.lib().cm_train_set_lr(self._handle, float(lr)))
+
+    def _mask_rows(self, B, drop_masks):
+        layout, width = self.dropout_layout()
+        row = np.ones((B, width), dtype=np.float32)
+        for prefix, off, cout in layout:
+            row[:, off:off + cout] = np.asarray(drop_masks[prefix], dtype=np.float32)
+        return row
+
+    def train_step(self, schedule_handle, future, past, t, eps, drop_masks=None, seed: int = 0,
+                   apply_update: bool = True) -> float:
+        """q-sample + train-mode forward + MSE + backward (+ Adam) on the device; returns the loss.
+        Inputs are numpy arrays (host staging) or native.DeviceBuffer objects already in HBM."""
+        L = native.lib()
+        dev = self.device
+
+        def dbuf(a, dtype):
+            if isinstance(a, native.DeviceBuffer):
+                return a
+            return native.DeviceBuffer.from_array(np.ascontiguousarray(a, dtype=dtype), dev)
+
+        B = int(t.nbytes // 8) if isinstance(t, native.DeviceBuffer) else int(np.asarray(t).size)
+        if not getattr(self, "_train_ready", False):
+            raise RuntimeError("train_init() has not been called")
+        dfut, dpst, deps = dbuf(future, np.float32), dbuf(past, np.float32), dbuf(eps, np.float32)
+        dt = dbuf(t, np.int64)
+        dmask = None
+        if drop_masks is not None:
+            dmask = dbuf(self._mask_rows(B, drop_masks) if isinstance(drop_masks, dict) else drop_masks, np.float32)
+        loss = C.c_float()
+        native.check(L.cm_train_step(self._handle, schedule_handle, dfut.ptr, dpst.ptr, dt.ptr, deps.ptr,
+                                     dmask.ptr if dmask else None, int(seed) & 0xFFFFFFFFFFFFFFFF, C.byref(loss), B,
+                                     1 if apply_update else 0, None))
+        return float(loss.value)
+
+    def grad(self, name: str) -> np.ndarray:
+        """Gradient of a state_dict tensor after the last train_step (reference layout)."""
+        shape = self._params[name].shape
+        out = np.empty(shape, dtype=np.float32)
+        native.check(native.lib().cm_train_get_grad(self._handle, name.encode(), out.ctypes.data, out.size))
+        return out
+
+    def sync_trained(self):
+        """Pull the trained master weights back into state_dict()."""
+        L = native.lib()
+        native.check(L.cm_train_sync(self._handle))
+        for name, arr in self._params.items():
+            out = np.empty(arr.shape, dtype=np.float32)
+            native.check(L.cm_model_get_param(self._handle, name.encode(), out.ctypes.data, out.size))
+            self._params[name] = out
 
     def mse_loss(self, pred, target) -> float:
         """F.mse_loss(pred, target) on the device (ddpm.py:120)."""

@@ -187,6 +187,28 @@ int cm_model_cost(const cm_model *m, int32_t B, double *flops, double *bytes);
 /* Algorithmic FLOPs of one forward per kernel class (same indices as cm_profile_read). */
 int cm_model_class_flops(const cm_model *m, int32_t B, double flops[8]);
 
+/* ---- training step: replaces DDPM_model._train_step + optimizer.step() -----
+ * (models/diffusion/ddpm.py:111-121,142-144; optimizer built at ddpm.py:53-56:
+ * torch.optim.Adam(lr, betas, weight_decay) -- L2 coupled into the gradient.)
+ * cm_train_init allocates master weights / gradients / Adam moments on the device
+ * (state_dict order) and the backward workspace; call once after cm_model_finalize. */
+int cm_train_init(cm_model *m, float lr, float beta1, float beta2, float eps, float weight_decay);
+int cm_train_set_lr(cm_model *m, float lr);
+/* One step on device buffers:
+ *   x_t = q_sample(d_future, d_t, d_eps)          (forward.py:29-35 with the caller's noise)
+ *   eps_hat = UNet(x_t, d_t, d_past) in train mode (Dropout3d masks: d_dropmask [B][width] or
+ *             NULL -> device Philox stream keyed by (seed, step))
+ *   *h_loss = mse(eps_hat, d_eps); backward; if apply_update != 0: Adam step + weight re-pack.
+ * Synchronous (returns after the step has finished). */
+int cm_train_step(cm_model *m, const cm_schedule *s, const float *d_future, const float *d_past,
+                  const int64_t *d_t, const float *d_eps, const float *d_dropmask, uint64_t seed,
+                  float *h_loss, int32_t B, int32_t apply_update, void *stream);
+/* Gradient of one state_dict tensor after the last cm_train_step (reference layout). */
+int cm_train_get_grad(cm_model *m, const char *name, float *h_out, int64_t numel);
+/* Copy the trained master weights back into the handle's state_dict (cm_model_get_param then
+ * returns them) and refresh the eval-mode time-embedding table. */
+int cm_train_sync(cm_model *m);
+
 #ifdef __cplusplus
 }
 #endif

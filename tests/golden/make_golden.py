@@ -316,8 +316,28 @@ def gen_train(out):
               "encoder_blocks.0.conv_1.weight", "decoder_blocks.7.normalize_1.weight",
               "time_embeddings.time_blocks.1.weight"):
         d[f"grad/{k}"] = dict(net.named_parameters())[k].grad.numpy()
+    # optimizer.step() of ddpm.py:53-56,142-144 (config/ATC.yml solver: lr 5e-5, betas (0.5, 0.999),
+    # weight_decay 0.003), two steps so that the moment buffers and the bias correction are exercised:
+    # the second step re-runs the same batch / masks on the updated weights
+    opt = torch.optim.Adam(net.parameters(), lr=5e-5, betas=(0.5, 0.999), weight_decay=0.003)
+    opt.step()
+    post = ("first.weight", "final.2.weight", "encoder_blocks.4.attention.mhsa.in_proj_weight",
+            "encoder_blocks.0.conv_1.weight", "decoder_blocks.7.normalize_1.weight", "decoder_blocks.5.upsample.1.weight",
+            "encoder_blocks.1.downsample.weight", "time_embeddings.time_blocks.3.weight", "bottleneck_blocks.0.dense_1.bias")
+    sd = net.state_dict()
+    for k in post:
+        d[f"post1/{k}"] = sd[k].detach().numpy().copy()
+    opt.zero_grad(set_to_none=True)
+    pred2 = net(xt, torch.from_numpy(t), torch.from_numpy(past))
+    loss2 = torch.nn.functional.mse_loss(pred2, e)
+    loss2.backward()
+    opt.step()
+    d["loss2"] = np.float32(loss2.item())
+    sd = net.state_dict()
+    for k in post:
+        d[f"post2/{k}"] = sd[k].detach().numpy().copy()
     np.savez_compressed(os.path.join(out, "train.npz"), **d)
-    print("train loss", float(loss))
+    print("train loss", float(loss), "second step", float(loss2))
 
 
 def main():
