@@ -60,6 +60,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
+  int tapoff[TW];
+#pragma unroll
+  for (int ti = 0; ti < TW; ++ti) {
+    const int t = min(wave + 4 * ti, ntaps - 1);
+    const int dz = t / (td * td), rem = t - dz * td * td, dyy = rem / td, dx = rem - dyy * td;
+    tapoff[ti] = ((dz * HY + dyy) * HX + dx) * 32;
+  }
   const int Zc = a.Zs << a.ups, Yc = a.Ys << a.ups, Xc = a.Xs << a.ups;
   for (int tile = g; tile < ntile; tile += G) {
     int tt = tile;
@@ -115,18 +122,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
       *reinterpret_cast<f32x4 *>(&at[hv * 32 + 4 * q]) = w;
     }
     __syncthreads();
+    // voxel pairs outermost, the wave's taps innermost: one dy value and one halo index feed up to
+    // seven independent accumulators, so the LDS reads of a pair are issued together
+#pragma unroll 2
+    for (int m0 = 0; m0 < TM; m0 += 2) {
+      const float av = dyt[(m0 + h) * 32 + r];
+      const int hb = rowhv[m0 + h] * 32 + r;
+      float bv[TW];
 #pragma unroll
-    for (int ti = 0; ti < TW; ++ti) {
-      const int t = wave + 4 * ti;
-      if (t < ntaps) {
-        const int dz = t / (td * td), rem = t - dz * td * td, dyy = rem / td, dx = rem - dyy * td;
-        const int tapoff = (dz * HY + dyy) * HX + dx;
-        for (int m0 = 0; m0 < TM; m0 += 2) {
-          const float av = dyt[(m0 + h) * 32 + r];
-          const float bv = at[(rowhv[m0 + h] + tapoff) * 32 + r];
-          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ti], 0, 0, 0);
-        }
-      }
+      for (int ti = 0; ti < TW; ++ti) bv[ti] = at[hb + tapoff[ti]];
+#pragma unroll
+      for (int ti = 0; ti < TW; ++ti)
+        if (wave + 4 * ti < ntaps) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[ti], acc[ti], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -165,27 +172,36 @@ hipError_t launch_wgrad(const ConvArgs &a, int MB, const float *dy, int dy_cs, f
 
 // part[g][cb][kb][tap][32 co][32 ci] summed over g (fixed order) -> reference weight layout
 // [Co][Ci][kH][kW][kL] (internal tap (dz,dy,dx) = reference [kH=dy][kW=dx][kL=dz]); 1 tap -> [Co][Ci].
+// Threads walk the PARTIAL layout (ci fastest) so the G reads per output are coalesced.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int G, int ncb, int nkb,
                                                            int ntaps, int Co, int Ci, float *__restrict__ dW) {
-  const long long total = (long long)Co * Ci * ntaps;
+  const long long per_g = (long long)ncb * nkb * ntaps * 1024;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int t = (int)(i % ntaps);
-  long long q = i / ntaps;
-  const int ci = (int)(q % Ci);
-  const int co = (int)(q / Ci);
-  const int cb = co >> 5, kb = ci >> 5;
-  float s = 0.f;
-  for (int g = 0; g < G; ++g)
-    s += part[((((size_t)g * ncb + cb) * nkb + kb) * ntaps + t) * 1024 + (co & 31) * 32 + (ci & 31)];
+  if (i >= per_g) return;
+  const int cil = (int)(i & 31), col = (int)((i >> 5) & 31);
+  long long q = i >> 10;
+  const int t = (int)(q % ntaps); q /= ntaps;
+  const int kb = (int)(q % nkb);
+  const int cb = (int)(q / nkb);
+  const int co = cb * 32 + col, ci = kb * 32 + cil;
+  if (co >= Co || ci >= Ci) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int g = 0;
+  for (; g + 3 < G; g += 4) {
+    s0 += part[(size_t)g * per_g + i];
+    s1 += part[(size_t)(g + 1) * per_g + i];
+    s2 += part[(size_t)(g + 2) * per_g + i];
+    s3 += part[(size_t)(g + 3) * per_g + i];
+  }
+  for (; g < G; ++g) s0 += part[(size_t)g * per_g + i];
   int tref = 0;
   if (ntaps == 27) { const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3; tref = (dy * 3 + dx) * 3 + dz; }
-  dW[((size_t)co * Ci + ci) * ntaps + tref] = s;
+  dW[((size_t)co * Ci + ci) * ntaps + tref] = (s0 + s1) + (s2 + s3);
 }
 
 hipError_t launch_wgrad_reduce(const float *part, int G, int ncb, int nkb, int ntaps, int Co, int Ci, float *dW,
                                hipStream_t st) {
-  const long long total = (long long)Co * Ci * ntaps;
+  const long long total = (long long)ncb * nkb * ntaps * 1024;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, G, ncb, nkb,
                      ntaps, Co, Ci, dW);
   return hipGetLastError();
@@ -201,39 +217,48 @@ __global__ __launch_bounds__(256) void voxel_sum_kernel(const float *__restrict_
                                                         float *__restrict__ out, int ostride) {
   __shared__ float sh[256];
   const int b = blockIdx.x, tid = threadIdx.x;
-  for (int c0 = 0; c0 < C; c0 += 32) {
-    const int c = c0 + (tid & 31), vl = tid >> 5;  // 8 voxel lanes
-    float s = 0.f;
-    if (c < C)
-      for (int v = vl; v < V; v += 8) s += x[((size_t)b * V + v) * cs + c];
-    sh[tid] = s;
-    __syncthreads();
-    if (tid < 32 && c < C) {
-      float t = 0.f;
-      for (int l = 0; l < 8; ++l) t += sh[l * 32 + tid];
-      out[(size_t)b * ostride + c] = t;
-    }
-    __syncthreads();
+  const int c = blockIdx.y * 32 + (tid & 31), vl = tid >> 5;  // 8 voxel lanes
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    const float *p = x + (size_t)b * V * cs + c;
+    int v = vl;
+    for (; v + 8 < V; v += 16) { s0 += p[(size_t)v * cs]; s1 += p[(size_t)(v + 8) * cs]; }
+    if (v < V) s0 += p[(size_t)v * cs];
+  }
+  sh[tid] = s0 + s1;
+  __syncthreads();
+  if (tid < 32 && c < C) {
+    float t = 0.f;
+    for (int l = 0; l < 8; ++l) t += sh[l * 32 + tid];
+    out[(size_t)b * ostride + c] = t;
   }
 }
 
 hipError_t launch_voxel_sum(const float *x, int B, int V, int C, int cs, float *out, int ostride, hipStream_t st) {
-  hipLaunchKernelGGL(voxel_sum_kernel, dim3(B), dim3(256), 0, st, x, V, C, cs, out, ostride);
+  hipLaunchKernelGGL(voxel_sum_kernel, dim3(B, (C + 31) / 32), dim3(256), 0, st, x, V, C, cs, out, ostride);
   return hipGetLastError();
 }
 
-// out[c] (+)= sum_b in[b][c]
-__global__ void batch_sum_kernel(const float *__restrict__ in, int B, int C, int stride, float *__restrict__ out,
-                                 int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+// out[c] (+)= sum_b in[b][c]; one workgroup per 32 channels, 8 sample lanes, fixed-order tree
+__global__ __launch_bounds__(256) void batch_sum_kernel(const float *__restrict__ in, int B, int C, int stride,
+                                                        float *__restrict__ out, int accumulate) {
+  __shared__ float sh[256];
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x * 32 + (tid & 31), bl = tid >> 5;
   float s = 0.f;
-  for (int b = 0; b < B; ++b) s += in[(size_t)b * stride + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < C)
+    for (int b = bl; b < B; b += 8) s += in[(size_t)b * stride + c];
+  sh[tid] = s;
+  __syncthreads();
+  if (tid < 32 && c < C) {
+    float t = 0.f;
+    for (int l = 0; l < 8; ++l) t += sh[l * 32 + tid];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 hipError_t launch_batch_sum(const float *in, int B, int C, int stride, float *out, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(batch_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, in, B, C, stride, out, accumulate);
+  hipLaunchKernelGGL(batch_sum_kernel, dim3((C + 31) / 32), dim3(256), 0, st, in, B, C, stride, out, accumulate);
   return hipGetLastError();
 }
 
@@ -558,84 +583,83 @@ hipError_t launch_attn_bwd(const float *qkv, const float *dO, float *dqkv, int B
 // index row b); the backward consumes dproj [B][nproj] and produces all weight gradients.
 // --------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void time_bwd_kernel(const TimeBwdArgs a) {
-  const int tid = threadIdx.x;
-  const int B = a.B, te = a.te, tx = a.tx, np = a.nproj;
-  float *e = a.ws, *h1 = e + (size_t)B * te, *z1 = h1 + (size_t)B * tx, *tev = z1 + (size_t)B * tx,
-        *sv = tev + (size_t)B * tx, *dte = sv + (size_t)B * tx, *dz1 = dte + (size_t)B * tx;
-  for (int i = tid; i < B * te; i += 256) e[i] = a.table[(size_t)a.t[i / te] * te + i % te];
+// forward recompute, one workgroup per sample
+__global__ __launch_bounds__(256) void time_fwd_rows_kernel(const TimeBwdArgs a) {
+  extern __shared__ float sm[];  // e[te], h1[tx]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int B = a.B, te = a.te, tx = a.tx;
+  float *e = a.ws, *h1 = e + (size_t)B * te, *z1 = h1 + (size_t)B * tx, *tev = z1 + (size_t)B * tx, *sv = tev + (size_t)B * tx;
+  float *es = sm, *hs = sm + te;
+  for (int k = tid; k < te; k += 256) { const float v = a.table[(size_t)a.t[b] * te + k]; es[k] = v; e[(size_t)b * te + k] = v; }
   __syncthreads();
-  for (int i = tid; i < B * tx; i += 256) {
-    const int b = i / tx, o = i % tx;
+  for (int o = tid; o < tx; o += 256) {
     float acc = a.b1[o];
-    for (int k = 0; k < te; ++k) acc = fmaf(a.W1[(size_t)o * te + k], e[b * te + k], acc);
-    z1[i] = acc;
-    h1[i] = acc * sigmoid_f(acc);
+    for (int k = 0; k < te; ++k) acc = fmaf(a.W1[(size_t)o * te + k], es[k], acc);
+    z1[(size_t)b * tx + o] = acc;
+    const float h = acc * sigmoid_f(acc);
+    hs[o] = h; h1[(size_t)b * tx + o] = h;
   }
   __syncthreads();
-  for (int i = tid; i < B * tx; i += 256) {
-    const int b = i / tx, o = i % tx;
+  for (int o = tid; o < tx; o += 256) {
     float acc = a.b2[o];
-    for (int k = 0; k < tx; ++k) acc = fmaf(a.W2[(size_t)o * tx + k], h1[b * tx + k], acc);
-    tev[i] = acc;
-    sv[i] = acc * sigmoid_f(acc);
-  }
-  __syncthreads();
-  // dWd[o][k] = sum_b dproj[b][o] * s[b][k] ; dbd[o] = sum_b dproj[b][o]
-  for (int i = tid; i < np * tx; i += 256) {
-    const int o = i / tx, k = i % tx;
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc = fmaf(a.dproj[(size_t)b * np + o], sv[b * tx + k], acc);
-    a.dWd[i] = acc;
-  }
-  for (int o = tid; o < np; o += 256) {
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc += a.dproj[(size_t)b * np + o];
-    a.dbd[o] = acc;
-  }
-  // dte[b][k] = (sum_o dproj[b][o] Wd[o][k]) * silu'(te)
-  for (int i = tid; i < B * tx; i += 256) {
-    const int b = i / tx, k = i % tx;
-    float acc = 0.f;
-    for (int o = 0; o < np; ++o) acc = fmaf(a.dproj[(size_t)b * np + o], a.Wd[(size_t)o * tx + k], acc);
-    const float y = tev[i], s = sigmoid_f(y);
-    dte[i] = acc * s * (1.0f + y * (1.0f - s));
-  }
-  __syncthreads();
-  for (int i = tid; i < tx * tx; i += 256) {
-    const int o = i / tx, k = i % tx;
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc = fmaf(dte[b * tx + o], h1[b * tx + k], acc);
-    a.dW2[i] = acc;
-  }
-  for (int o = tid; o < tx; o += 256) {
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc += dte[b * tx + o];
-    a.db2[o] = acc;
-  }
-  for (int i = tid; i < B * tx; i += 256) {
-    const int b = i / tx, k = i % tx;
-    float acc = 0.f;
-    for (int o = 0; o < tx; ++o) acc = fmaf(dte[b * tx + o], a.W2[(size_t)o * tx + k], acc);
-    const float y = z1[i], s = sigmoid_f(y);
-    dz1[i] = acc * s * (1.0f + y * (1.0f - s));
-  }
-  __syncthreads();
-  for (int i = tid; i < tx * te; i += 256) {
-    const int o = i / te, k = i % te;
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc = fmaf(dz1[b * tx + o], e[b * te + k], acc);
-    a.dW1[i] = acc;
-  }
-  for (int o = tid; o < tx; o += 256) {
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc += dz1[b * tx + o];
-    a.db1[o] = acc;
+    for (int k = 0; k < tx; ++k) acc = fmaf(a.W2[(size_t)o * tx + k], hs[k], acc);
+    tev[(size_t)b * tx + o] = acc;
+    sv[(size_t)b * tx + o] = acc * sigmoid_f(acc);
   }
 }
 
+// C[m][n] = sum_k A[m*sam + k*sak] * Bm[k*sbk + n]   (* silu'(pre[m][n]) when pre != null); one thread per
+// output, n fastest: B reads coalesced, A reads broadcast within a row of threads.
+__global__ __launch_bounds__(256) void small_gemm_kernel(const float *__restrict__ A, long long sam, long long sak,
+                                                         const float *__restrict__ Bm, long long sbk,
+                                                         float *__restrict__ Cm, int M, int N, int K,
+                                                         const float *__restrict__ pre) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)M * N) return;
+  const int n = (int)(i % N);
+  const long long m = i / N;
+  const float *ap = A + m * sam;
+  const float *bp = Bm + n;
+  float acc0 = 0.f, acc1 = 0.f;
+  int k = 0;
+  for (; k + 1 < K; k += 2) {
+    acc0 = fmaf(ap[(long long)k * sak], bp[(long long)k * sbk], acc0);
+    acc1 = fmaf(ap[(long long)(k + 1) * sak], bp[(long long)(k + 1) * sbk], acc1);
+  }
+  if (k < K) acc0 = fmaf(ap[(long long)k * sak], bp[(long long)k * sbk], acc0);
+  float v = acc0 + acc1;
+  if (pre) { const float y = pre[i], sg = sigmoid_f(y); v *= sg * (1.0f + y * (1.0f - sg)); }
+  Cm[i] = v;
+}
+
+static void small_gemm(const float *A, long long sam, long long sak, const float *Bm, long long sbk, float *Cm, int M,
+                       int N, int K, const float *pre, hipStream_t st) {
+  const long long total = (long long)M * N;
+  hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A, sam, sak, Bm, sbk, Cm,
+                     M, N, K, pre);
+}
+
 hipError_t launch_time_bwd(const TimeBwdArgs &a, hipStream_t st) {
-  hipLaunchKernelGGL(time_bwd_kernel, dim3(1), dim3(256), 0, st, a);
+  const int B = a.B, te = a.te, tx = a.tx, np = a.nproj;
+  float *e = a.ws, *h1 = e + (size_t)B * te, *z1 = h1 + (size_t)B * tx, *tev = z1 + (size_t)B * tx,
+        *sv = tev + (size_t)B * tx, *dte = sv + (size_t)B * tx, *dz1 = dte + (size_t)B * tx;
+  hipLaunchKernelGGL(time_fwd_rows_kernel, dim3(B), dim3(256), (size_t)(te + tx) * sizeof(float), st, a);
+  // dWd[o][k] = sum_b dproj[b][o] * s[b][k] ; dbd[o] = sum_b dproj[b][o]
+  small_gemm(a.dproj, 1, np, sv, tx, a.dWd, np, tx, B, nullptr, st);
+  hipError_t err = launch_batch_sum(a.dproj, B, np, np, a.dbd, 0, st);
+  if (err != hipSuccess) return err;
+  // dte[b][k] = (sum_o dproj[b][o] Wd[o][k]) * silu'(te[b][k])
+  small_gemm(a.dproj, np, 1, a.Wd, tx, dte, B, tx, np, tev, st);
+  // dW2[o][k] = sum_b dte[b][o] h1[b][k] ; db2
+  small_gemm(dte, 1, tx, h1, tx, a.dW2, tx, tx, B, nullptr, st);
+  err = launch_batch_sum(dte, B, tx, tx, a.db2, 0, st);
+  if (err != hipSuccess) return err;
+  // dz1[b][k] = (sum_o dte[b][o] W2[o][k]) * silu'(z1[b][k])
+  small_gemm(dte, tx, 1, a.W2, tx, dz1, B, tx, tx, z1, st);
+  // dW1[o][k] = sum_b dz1[b][o] e[b][k] ; db1
+  small_gemm(dz1, 1, tx, e, te, a.dW1, tx, te, B, nullptr, st);
+  err = launch_batch_sum(dz1, B, tx, tx, a.db1, 0, st);
+  if (err != hipSuccess) return err;
   return hipGetLastError();
 }
 
