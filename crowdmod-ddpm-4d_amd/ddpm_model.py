@@ -23,6 +23,30 @@ from .diffusion import DDPM
 from .unet import UNet, _is_torch
 
 
+class ReduceLROnPlateau:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', threshold=1e-4 relative, cooldown 0) as the
+    reference configures it (ddpm.py:58-63): after `patience` epochs without a relative improvement of
+    1e-4 the rate is multiplied by `factor`, never below `min_lr`."""
+
+    def __init__(self, lr, factor=0.5, patience=10, min_lr=0.0, threshold=1e-4, eps=1e-8):
+        self.lr, self.factor, self.patience, self.min_lr = float(lr), float(factor), int(patience), float(min_lr)
+        self.threshold, self.eps = float(threshold), float(eps)
+        self.best, self.bad = float("inf"), 0
+
+    def step(self, metric: float) -> float:
+        m = float(metric)
+        if m < self.best * (1.0 - self.threshold):
+            self.best, self.bad = m, 0
+        else:
+            self.bad += 1
+        if self.bad > self.patience:
+            new_lr = max(self.lr * self.factor, self.min_lr)
+            if self.lr - new_lr > self.eps:
+                self.lr = new_lr
+            self.bad = 0
+        return self.lr
+
+
 class DDPM_model:
     def __init__(self, cfg, arch, mprops_count, output_dir=None, from_fixed_past=False, *, device: int = 0,
                  seed: int = 42):
@@ -169,6 +193,117 @@ class DDPM_model:
         finally:
             self.denoiser.eval()
         return self.denoiser.mse_loss(pred, eps), pred
+
+    # -- training (ddpm.py:123-202) ---------------------------------------------------
+    def _solver(self):
+        tr = self.res.train or {}
+        sol = tr.get("SOLVER", {}) if hasattr(tr, "get") else {}
+        sch = sol.get("SCHEDULER", {}) if hasattr(sol, "get") else {}
+        return {
+            "epochs": int(tr.get("EPOCHS", 1)) if hasattr(tr, "get") else 1,
+            "lr": float(sol.get("LR", 5e-5)), "betas": tuple(float(b) for b in sol.get("BETAS", (0.5, 0.999))),
+            "weight_decay": float(sol.get("WEIGHT_DECAY", 0.0)),
+            "factor": float(sch.get("FACTOR", 0.5)), "patience": int(sch.get("PATIENCE", 10)),
+            "min_lr": float(sch.get("MIN_LR", 0.0)),
+        }
+
+    def _ensure_training(self, past, future):
+        net = self.denoiser
+        B, _, H, W, F = future.shape
+        net.ensure(H, W, int(past.shape[4]), F, B)
+        if not getattr(net, "_train_ready", False):
+            s = self._solver()
+            net.train_init(lr=s["lr"], betas=s["betas"], weight_decay=s["weight_decay"])
+            self._lr = s["lr"]
+            self._plateau = ReduceLROnPlateau(s["lr"], s["factor"], s["patience"], s["min_lr"])
+
+    def _train_one_epoch(self, forward_sampler: DDPM, loader, epoch, *, rng: Optional[np.random.Generator] = None,
+                         grad_sync=None):
+        """ddpm.py:123-154: for every (past, future) batch: t ~ U{0..T-1}, q-sample with device-drawn
+        noise, train-mode forward, MSE, backward, Adam -- one native call per batch.  `grad_sync`, when
+        given, is called between backward and update (data-parallel gradient averaging).
+        Returns the mean batch loss (MeanMetric)."""
+        rng = rng or np.random.default_rng(self.seed + epoch)
+        total, count = 0.0, 0
+        for past, future in loader:
+            past = np.ascontiguousarray(past, dtype=np.float32)
+            future = np.ascontiguousarray(future, dtype=np.float32)
+            self._ensure_training(past, future)
+            t = rng.integers(0, forward_sampler.timesteps, size=(future.shape[0],)).astype(np.int64)
+            self._train_calls = getattr(self, "_train_calls", 0) + 1
+            if grad_sync is None:
+                loss = self.denoiser.train_step(forward_sampler._handle, future, past, t, None,
+                                                seed=self.seed + self._train_calls, apply_update=True)
+            else:
+                loss = self.denoiser.train_step(forward_sampler._handle, future, past, t, None,
+                                                seed=self.seed + self._train_calls, apply_update=False)
+                grad_sync(self.denoiser)
+                self.denoiser.apply_update()
+            total += loss
+            count += 1
+        return total / max(count, 1)
+
+    def checkpoint_path(self, epoch_tag) -> str:
+        """utils/utils.py:120-138: SAVE_DIR + NAME.format(arch, EPOCHS, PAST_LEN, FUTURE_LEN, tag, 'NA')."""
+        import os
+        name = self.cfg.MODEL.NAME.format(self.arch, self._solver()["epochs"], self.res.past_len, self.res.future_len,
+                                          epoch_tag, "NA")
+        return os.path.join(self.cfg.DATA_FS.SAVE_DIR, name)
+
+    def save_checkpoint(self, epoch_tag, path: Optional[str] = None) -> str:
+        """utils/utils.py:140-147: {"opt": optimizer.state_dict(), "model": model.state_dict()} as a torch
+        zip checkpoint the reference reads with torch.load(path, weights_only=True)."""
+        import os
+        from . import checkpoint
+        s = self._solver()
+        net = self.denoiser
+        net.sync_trained()
+        path = path or self.checkpoint_path(epoch_tag)
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        opt = net.optimizer_state_dict(getattr(self, "_lr", s["lr"]), s["betas"], 1e-8, s["weight_decay"])
+        checkpoint.save_checkpoint(net.state_dict(), path, opt_state=opt)
+        return path
+
+    def train(self, batched_train_data, baseline_ckpt=None, *, log=None, grad_sync=None, save=True):
+        """ddpm.py:156-202: epochs of _train_one_epoch, ReduceLROnPlateau on the epoch loss, NaN early
+        stop, best-loss checkpoint tagged "000" and CHECKPOINTS_TO_KEEP random late epochs."""
+        import logging
+        forward_sampler = DDPM(timesteps=self.res.timesteps, scale=self.res.scale, device=self.device)
+        if baseline_ckpt is not None:
+            self.load_checkpoint(baseline_ckpt)
+            logging.info("Baseline checkpoint loaded successfully.")
+        s = self._solver()
+        epochs = s["epochs"]
+        best_loss, nan_run = 1e6, 0
+        keep = int(self.cfg.MODEL.get("DDPM", {}).get("CHECKPOINTS_TO_KEEP", 0) or 0)
+        rng = np.random.default_rng(self.seed)
+        to_save = set(int(v) for v in rng.integers(int(epochs * 0.75), epochs + 1, size=keep)) if keep else set()
+        history = []
+        for epoch in range(1, epochs + 1):
+            epoch_loss = self._train_one_epoch(forward_sampler, batched_train_data, epoch, grad_sync=grad_sync)
+            history.append(epoch_loss)
+            if log:
+                log({"train_loss": epoch_loss, "epoch": epoch, "lr": self._lr})
+            new_lr = self._plateau.step(epoch_loss)
+            if new_lr != self._lr:
+                self._lr = new_lr
+                self.denoiser.set_lr(new_lr)
+            if np.isnan(epoch_loss):
+                nan_run += 1
+                logging.warning("Epoch %d: loss is NaN (%d consecutive)", epoch, nan_run)
+                if nan_run >= 3:
+                    logging.error("Loss has been NaN for 3 consecutive epochs; terminating training early.")
+                    break
+            else:
+                nan_run = 0
+            if save and epoch_loss < best_loss:
+                best_loss = epoch_loss
+                self.save_checkpoint("000")
+            if save and epoch in to_save:
+                logging.info("Epoch %d: in checkpoints_to_keep set, saving model.", epoch)
+                self.save_checkpoint(epoch)
+        self.denoiser.sync_trained()
+        return history
 
     def load_checkpoint(self, model_fullname: str):
         """ddpm.py:288: load_state_dict(torch.load(path, map_location='cpu', weights_only=True)['model'])."""

@@ -90,6 +90,11 @@ SIGNATURES = {
     "cm_train_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_float), C.c_int32, C.c_int32, _P]),
     "cm_train_get_grad": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     "cm_train_sync": (C.c_int, [_P]),
+    "cm_train_flat_grads": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "cm_train_apply": (C.c_int, [_P, _P]),
+    "cm_train_get_opt_state": (C.c_int, [_P, C.c_char_p, C.c_int32, _P, C.c_int64]),
+    "cm_train_set_opt_state": (C.c_int, [_P, C.c_char_p, C.c_int32, _P, C.c_int64]),
+    "cm_train_opt_step": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32]),
 }
 
 

@@ -239,13 +239,15 @@ class UNet:
         B = int(t.nbytes // 8) if isinstance(t, native.DeviceBuffer) else int(np.asarray(t).size)
         if not getattr(self, "_train_ready", False):
             raise RuntimeError("train_init() has not been called")
-        dfut, dpst, deps = dbuf(future, np.float32), dbuf(past, np.float32), dbuf(eps, np.float32)
+        dfut, dpst = dbuf(future, np.float32), dbuf(past, np.float32)
+        deps = dbuf(eps, np.float32) if eps is not None else None  # None: drawn on the device
         dt = dbuf(t, np.int64)
         dmask = None
         if drop_masks is not None:
             dmask = dbuf(self._mask_rows(B, drop_masks) if isinstance(drop_masks, dict) else drop_masks, np.float32)
         loss = C.c_float()
-        native.check(L.cm_train_step(self._handle, schedule_handle, dfut.ptr, dpst.ptr, dt.ptr, deps.ptr,
+        native.check(L.cm_train_step(self._handle, schedule_handle, dfut.ptr, dpst.ptr, dt.ptr,
+                                     deps.ptr if deps else None,
                                      dmask.ptr if dmask else None, int(seed) & 0xFFFFFFFFFFFFFFFF, C.byref(loss), B,
                                      1 if apply_update else 0, None))
         return float(loss.value)
@@ -256,6 +258,57 @@ class UNet:
         out = np.empty(shape, dtype=np.float32)
         native.check(native.lib().cm_train_get_grad(self._handle, name.encode(), out.ctypes.data, out.size))
         return out
+
+    def flat_grads(self):
+        """(device pointer, numel) of the flat fp32 gradient buffer in state_dict order (data-parallel
+        all-reduce between train_step(apply_update=False) and apply_update())."""
+        ptr, n = C.c_void_p(), C.c_int64()
+        native.check(native.lib().cm_train_flat_grads(self._handle, C.byref(ptr), C.byref(n)))
+        return ptr.value, int(n.value)
+
+    def apply_update(self):
+        native.check(native.lib().cm_train_apply(self._handle, None))
+
+    def trainable_names(self):
+        """Names in model.parameters() order; index 0 (the frozen sinusoid table) carries no Adam state."""
+        return list(self._params.keys())
+
+    def optimizer_state_dict(self, lr: float, betas, eps: float, weight_decay: float):
+        """torch.optim.Adam.state_dict() of the reference optimizer (ddpm.py:53-56): what
+        save_checkpoint stores under "opt" (utils/utils.py:140-147)."""
+        L = native.lib()
+        step = C.c_int32()
+        native.check(L.cm_train_opt_step(self._handle, C.byref(step), 0))
+        names = self.trainable_names()
+        state = {}
+        if step.value > 0:
+            for i, name in enumerate(names):
+                if i == 0:
+                    continue  # requires_grad=False: the optimizer never created state for it
+                shp = self._params[name].shape
+                m1, m2 = np.empty(shp, np.float32), np.empty(shp, np.float32)
+                native.check(L.cm_train_get_opt_state(self._handle, name.encode(), 0, m1.ctypes.data, m1.size))
+                native.check(L.cm_train_get_opt_state(self._handle, name.encode(), 1, m2.ctypes.data, m2.size))
+                state[i] = {"step": np.float32(step.value), "exp_avg": m1, "exp_avg_sq": m2}
+        group = {"lr": float(lr), "betas": (float(betas[0]), float(betas[1])), "eps": float(eps),
+                 "weight_decay": float(weight_decay), "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, opt: dict):
+        """Inverse of optimizer_state_dict (resume from a checkpoint's "opt" entry)."""
+        L = native.lib()
+        names = self.trainable_names()
+        step = 0
+        for i, st in opt.get("state", {}).items():
+            name = names[int(i)]
+            for which, key in ((0, "exp_avg"), (1, "exp_avg_sq")):
+                arr = np.ascontiguousarray(np.asarray(st[key]), dtype=np.float32)
+                native.check(L.cm_train_set_opt_state(self._handle, name.encode(), which, arr.ctypes.data, arr.size))
+            step = max(step, int(np.asarray(st["step"]).reshape(-1)[0]))
+        cs = C.c_int32(step)
+        native.check(L.cm_train_opt_step(self._handle, C.byref(cs), 1))
 
     def sync_trained(self):
         """Pull the trained master weights back into state_dict()."""

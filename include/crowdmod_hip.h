@@ -203,6 +203,17 @@ int cm_train_set_lr(cm_model *m, float lr);
 int cm_train_step(cm_model *m, const cm_schedule *s, const float *d_future, const float *d_past,
                   const int64_t *d_t, const float *d_eps, const float *d_dropmask, uint64_t seed,
                   float *h_loss, int32_t B, int32_t apply_update, void *stream);
+/* d_eps may be NULL: eps ~ N(0,1) is then drawn from the device Philox stream (seed, step, sample),
+ * the analogue of torch.randn_like in forward.py:33.
+ * Data-parallel use: cm_train_step(apply_update=0) on every rank, all-reduce(mean) the flat gradient
+ * buffer from cm_train_flat_grads, then cm_train_apply (Adam + re-pack). */
+int cm_train_flat_grads(cm_model *m, void **d_grads, int64_t *numel);
+int cm_train_apply(cm_model *m, void *stream);
+/* Adam state for the "opt" entry of a checkpoint (utils/utils.py:140-147): which = 0 exp_avg,
+ * 1 exp_avg_sq; cm_train_opt_step reads (set=0) or writes (set=1) the step counter. */
+int cm_train_get_opt_state(cm_model *m, const char *name, int32_t which, float *h_out, int64_t numel);
+int cm_train_set_opt_state(cm_model *m, const char *name, int32_t which, const float *h_in, int64_t numel);
+int cm_train_opt_step(cm_model *m, int32_t *step, int32_t set);
 /* Gradient of one state_dict tensor after the last cm_train_step (reference layout). */
 int cm_train_get_grad(cm_model *m, const char *name, float *h_out, int64_t numel);
 /* Copy the trained master weights back into the handle's state_dict (cm_model_get_param then

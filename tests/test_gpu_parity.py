@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path (through the C ABI) vs the golden vectors captured
 from the reference and vs the oracle.  Run on the MI355X box with `-m gpu`."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -270,6 +271,18 @@ def test_training_backward_gradients_vs_reference():
             # GroupNorm) hold rounding noise of order 1e-8 on both sides: absolute floor
             assert abs(got - ref) <= 1e-3 * ref + 2e-7, (name, got, ref)
     assert len(worst) == 168  # every state_dict tensor except the frozen sinusoid table
+    # the flat gradient buffer the data-parallel all-reduce works on: zero-copy torch view (RCCL reduces
+    # this tensor in place), laid out in state_dict order
+    import torch
+    from crowdmod_ddpm_4d_amd.distributed import _DevView
+    ptr, n = net.flat_grads()
+    view = torch.as_tensor(_DevView(ptr, n), device="cuda:0")
+    assert view.data_ptr() == ptr and view.numel() == sum(v.size for v in net.state_dict().values())
+    off = 0
+    for name, v in net.state_dict().items():
+        if name == "final.2.weight":
+            assert np.array_equal(view[off:off + v.size].cpu().numpy().reshape(v.shape), net.grad(name))
+        off += v.size
 
 
 @pytest.mark.gpu
@@ -305,3 +318,64 @@ def test_training_two_adam_steps_vs_reference():
     ref = onp.unet_forward(sd, spec.make_plan(narrow_cfg(3)), fut, t, past)
     assert np.abs(out - ref).max() <= TOL
 
+
+@pytest.mark.gpu
+def test_train_loop_checkpoint_and_resume(tmp_path):
+    """DDPM_model.train (ddpm.py:156-202) on a small synthetic set: the loss falls, the best-loss
+    checkpoint is written under the reference's file name in the reference's {"opt","model"} format,
+    torch reads it back, and a fresh handle resumed from it (weights + Adam state) continues bit-exactly."""
+    import torch
+    from crowdmod_ddpm_4d_amd import checkpoint
+    from crowdmod_ddpm_4d_amd.config import AttrDict
+    from crowdmod_ddpm_4d_amd.ddpm_model import DDPM_model
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    B, C_ = 8, 3
+    H, W, P, F = NARROW["H"], NARROW["W"], NARROW["P"], NARROW["F"]
+
+    def make():
+        cfg = AttrDict({
+            "MACROPROPS": {"ROWS": H, "COLS": W},
+            "DATASET": {"NAME": "synthetic", "PAST_LEN": P, "FUTURE_LEN": F, "BATCH_SIZE": B},
+            "DATA_FS": {"SAVE_DIR": str(tmp_path) + "/"},
+            "MODEL": {"NAME": "{}_SYN_TE{}_PL{}_FL{}_CE{}_{}.pth", "DDPM": {"TIMESTEPS": 1000, "SCALE": 0.5,
+                      "CHECKPOINTS_TO_KEEP": 1, "UNET": {
+                          "CONDITION": "Past", "NUM_RES_BLOCKS": 1, "BASE_CH": 8, "BASE_CH_MULT": [1, 2, 4],
+                          "APPLY_ATTENTION": [False, False, True, False], "DROPOUT_RATE": 0.1, "TIME_EMB_MULT": 4,
+                          "TRAIN": {"EPOCHS": 4, "SOLVER": {"LR": 2e-3, "BETAS": [0.5, 0.999], "WEIGHT_DECAY": 0.003,
+                                    "SCHEDULER": {"FACTOR": 0.5, "PATIENCE": 10, "MIN_LR": 1e-6}}}}}}})
+        m = DDPM_model(cfg, "DDPM-UNet", C_)
+        m.denoiser.load_state_dict(spec.init_params(narrow_cfg(C_), SEED_W))
+        return m
+    n = 6 * B
+    past = prng.normal(3, "tl/past", n * C_ * H * W * P).reshape(n, C_, H, W, P)
+    fut = prng.normal(3, "tl/fut", n * C_ * H * W * F).reshape(n, C_, H, W, F)
+    loader = [(past[i:i + B], fut[i:i + B]) for i in range(0, n, B)]
+    m = make()
+    hist = m.train(loader)
+    assert len(hist) == 4 and all(np.isfinite(hist)) and hist[-1] < 0.8 * hist[0], hist
+    best = m.checkpoint_path("000")
+    assert best.endswith("DDPM-UNet_SYN_TE4_PL%d_FL%d_CE000_NA.pth" % (P, F)) and os.path.isfile(best)
+    ck = torch.load(best, map_location="cpu", weights_only=True)
+    assert set(ck.keys()) == {"opt", "model"} and len(ck["model"]) == 169
+    assert len(ck["opt"]["state"]) == 168 and ck["opt"]["param_groups"][0]["betas"] == (0.5, 0.999)
+    sd = m.denoiser.state_dict()
+    assert not np.array_equal(sd["final.2.weight"], spec.init_params(narrow_cfg(C_), SEED_W)["final.2.weight"])
+    # resume: weights + Adam moments + step counter from the file, then one more identical step on both
+    m.save_checkpoint("resume", path=str(tmp_path / "resume.pth"))
+    ck = torch.load(str(tmp_path / "resume.pth"), map_location="cpu", weights_only=True)
+    assert np.array_equal(ck["model"]["final.2.weight"].numpy(), sd["final.2.weight"])
+    assert float(ck["opt"]["state"][5]["step"]) == 24.0
+    m2 = make()
+    m2.load_checkpoint(str(tmp_path / "resume.pth"))
+    m2._ensure_training(past[:B], fut[:B])
+    m2.denoiser.load_optimizer_state_dict(checkpoint.load(str(tmp_path / "resume.pth"))["opt"])
+    sampler = DDPM(timesteps=1000, scale=0.5)
+    t = np.arange(B, dtype=np.int64) * 100
+    eps = prng.normal(3, "tl/eps", fut[:B].size).reshape(fut[:B].shape)
+    out = []
+    for mm in (m, m2):
+        l = mm.denoiser.train_step(sampler._handle, fut[:B], past[:B], t, eps, seed=99, apply_update=True)
+        mm.denoiser.sync_trained()
+        out.append((l, mm.denoiser.state_dict()["encoder_blocks.0.conv_1.weight"].copy()))
+    assert abs(out[0][0] - out[1][0]) <= 1e-6 * max(1.0, abs(out[0][0]))
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-7

@@ -251,3 +251,97 @@ def test_gloo_two_ranks_sharded_sampling_equals_single_process(tmp_path, gb):
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), f"r{r}.npy"))
         assert np.array_equal(got, want), r
+
+
+def test_plateau_scheduler_matches_torch():
+    """ReduceLROnPlateau(mode='min', factor, patience, min_lr) as the reference builds it (ddpm.py:58-63)."""
+    import torch
+    from crowdmod_ddpm_4d_amd.ddpm_model import ReduceLROnPlateau
+    p = [torch.nn.Parameter(torch.zeros(1))]
+    o = torch.optim.SGD(p, lr=5e-5)
+    ts = torch.optim.lr_scheduler.ReduceLROnPlateau(o, mode="min", factor=0.5, patience=3, min_lr=1e-6)
+    mine = ReduceLROnPlateau(5e-5, 0.5, 3, 1e-6)
+    rng = np.random.default_rng(3)
+    for i in range(120):
+        v = 1.0 / (1 + 0.05 * i) + (0.2 if i > 20 else 0.0) + 0.01 * rng.random()
+        ts.step(v)
+        assert abs(o.param_groups[0]["lr"] - mine.step(v)) < 1e-18, i
+
+
+def test_checkpoint_opt_entry_loads_into_torch_adam(tmp_path):
+    """The "opt" entry written next to "model" (utils/utils.py:140-147) must be a torch.optim.Adam
+    state_dict the reference can resume from: torch.load(weights_only=True) + load_state_dict."""
+    import torch
+    from crowdmod_ddpm_4d_amd import checkpoint
+    shapes = {"a.weight": (4, 3), "b.weight": (5,), "c.bias": (2, 2, 2)}
+    model = {k: np.arange(int(np.prod(s)), dtype=np.float32).reshape(s) for k, s in shapes.items()}
+    names = list(shapes)
+    state = {i: {"step": np.float32(7), "exp_avg": np.full(shapes[n], 0.5, np.float32),
+                 "exp_avg_sq": np.full(shapes[n], 0.25, np.float32)} for i, n in enumerate(names) if i > 0}
+    group = {"lr": 2.5e-5, "betas": (0.5, 0.999), "eps": 1e-8, "weight_decay": 0.003, "amsgrad": False,
+             "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+             "decoupled_weight_decay": False, "params": [0, 1, 2]}
+    path = str(tmp_path / "ck.pth")
+    checkpoint.save_checkpoint(model, path, opt_state={"state": state, "param_groups": [group]})
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    params = [torch.nn.Parameter(torch.from_numpy(model[n].copy())) for n in names]
+    params[0].requires_grad_(False)
+    opt = torch.optim.Adam(params, lr=1.0, betas=(0.9, 0.9), weight_decay=0.0)
+    opt.load_state_dict(ck["opt"])
+    assert opt.param_groups[0]["lr"] == 2.5e-5 and tuple(opt.param_groups[0]["betas"]) == (0.5, 0.999)
+    assert float(opt.state[params[1]]["step"]) == 7.0
+    assert torch.equal(opt.state[params[2]]["exp_avg_sq"], torch.full((2, 2, 2), 0.25))
+    assert params[0] not in opt.state
+    # and our own reader returns the same structure
+    back = checkpoint.load(path)
+    assert set(back["opt"]["state"].keys()) == {1, 2}
+    assert np.array_equal(back["model"]["c.bias"], model["c.bias"])
+
+
+def _dp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from crowdmod_ddpm_4d_amd import distributed as cdist
+    import crowdmod_ddpm_4d_amd.native as native
+    cdist.init_process_group("gloo")
+    # stand-in for the device buffer: the averager's host path only needs memcpy d2h / h2d
+    buf = np.full(1000, float(rank + 1), dtype=np.float32)
+
+    class FakeLib:
+        def cm_memcpy_d2h(self, dev, dst, src, nbytes):
+            C.memmove(dst, src, nbytes)
+            return 0
+
+        def cm_memcpy_h2d(self, dev, dst, src, nbytes):
+            C.memmove(dst, src, nbytes)
+            return 0
+
+    native.lib = lambda: FakeLib()
+    native.check = lambda rc: None
+
+    class Net:
+        device = 0
+
+        def flat_grads(self):
+            return buf.ctypes.data, buf.size
+
+    cdist.GradAverager()(Net())
+    q.put((rank, float(buf[0]), float(buf[-1])))
+    dist.destroy_process_group()
+
+
+def test_gradient_averaging_two_ranks_gloo():
+    """Data-parallel training: mean of the flat gradient buffers over 2 ranks (gloo on CPU; the GPU path
+    reduces the same buffer in place with RCCL)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500)
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert res == [(0, 1.5, 1.5), (1, 1.5, 1.5)]
