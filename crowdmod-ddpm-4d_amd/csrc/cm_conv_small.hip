@@ -1,0 +1,157 @@
+// 3x3x3 convolution with very few output channels (the UNet's last layer, unet.py:118-122:
+// GroupNorm -> SiLU -> Conv3d(base -> C), C = 3 or 4).  On the matrix cores a 32-wide N tile would
+// carry 28 padding columns, i.e. 8x the useful work; here every thread owns one output voxel and its
+// NCO accumulators on the vector ALUs instead:
+//   - the halo box is staged into LDS exactly like the implicit-GEMM kernel does (GroupNorm affine
+//     and SiLU applied on the way in), row stride CK + 4 floats;
+//   - the weights of the chunk sit in LDS as [tap][ci][NCO] and are read as wave-uniform
+//     (broadcast) vectors;
+//   - the 27 taps are split over the 256 / TM thread groups of the tile and the partial sums are
+//     merged through LDS in a fixed order.
+// Bound: VALU (4 * NCO FMAs per 16-byte LDS read), ~3 us of math per 128-voxel tile against
+// ~17 us of MFMA time for the padded tile.
+#include "cm_kernels.h"
+
+namespace cm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float silu_s(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+template <int NCO>
+__global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvArgs a, const float *__restrict__ wsm, int TM) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  int tile = blockIdx.x;
+  const int tx = tile % a.ntx; tile /= a.ntx;
+  const int ty = tile % a.nty; tile /= a.nty;
+  const int tz = tile % a.ntz;
+  const int b = tile / a.ntz;
+  const int z0 = tz * a.bz, y0 = ty * a.by, x0 = tx * a.bx;
+  const int HZ = a.bz + 2, HY = a.by + 2, HX = a.bx + 2;
+  const int HV = HZ * HY * HX;
+  const int S = a.CK + 4;
+  const int Ctot = a.C0 + a.C1;
+  const int nchunks = a.nch0 + a.nch1;
+  const int NG = 256 / TM;                     // tap groups (threads per output voxel)
+
+  float *A = lds;                              // [HV][S]
+  float *W = A + (size_t)HV * S;               // [27][CK][NCO]
+  float *red = W + 27 * a.CK * NCO;            // [NG - 1][TM][NCO]
+
+  // this thread's output voxel
+  const int m = tid % TM, grp = tid / TM;
+  const int pk = a.mtab[m];
+  int off = -1, hbase = 0;
+  if (pk >= 0) {
+    const int x = pk & 511, y = (pk >> 9) & 511, z = (pk >> 18) & 255;
+    const int oz = z0 + z, oy = y0 + y, ox = x0 + x;
+    if (oz < a.Zo && oy < a.Yo && ox < a.Xo) off = ((b * a.Zo + oz) * a.Yo + oy) * a.Xo + ox;
+    hbase = ((z * HY + y) * HX + x) * S;
+  }
+  const int t0 = grp * 27 / NG, t1 = (grp + 1) * 27 / NG;
+
+  float acc[NCO];
+#pragma unroll
+  for (int i = 0; i < NCO; ++i) acc[i] = 0.f;
+
+  const int K4 = a.CK >> 2;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float *src;
+    int Cs, c0, cg0;
+    if (ch < a.nch0) { src = a.src0; Cs = a.C0; c0 = ch * a.CK; cg0 = c0; }
+    else { src = a.src1; Cs = a.C1; c0 = (ch - a.nch0) * a.CK; cg0 = a.C0 + c0; }
+    __syncthreads();
+    for (int i = tid; i < 27 * a.CK * NCO; i += 256) W[i] = wsm[(size_t)ch * 27 * a.CK * NCO + i];
+    for (int i = tid; i < HV * K4; i += 256) {
+      const int hv = i / K4, q = i - hv * K4;
+      const int hp = a.hvtab[hv];
+      const int cx = x0 - 1 + (hp & 511), cy = y0 - 1 + ((hp >> 9) & 511), cz = z0 - 1 + ((hp >> 18) & 255);
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs) {
+        const size_t so = ((size_t)(b * a.Zs + cz) * a.Ys + cy) * a.Xs + cx;
+        w = *reinterpret_cast<const f32x4 *>(src + so * Cs + c0 + 4 * q);
+        if (a.gn) {
+          const float *g = a.gn + (size_t)b * 2 * Ctot + cg0 + 4 * q;
+          w = w * *reinterpret_cast<const f32x4 *>(g) + *reinterpret_cast<const f32x4 *>(g + Ctot);
+          if (a.silu) { w[0] = silu_s(w[0]); w[1] = silu_s(w[1]); w[2] = silu_s(w[2]); w[3] = silu_s(w[3]); }
+        }
+        if (a.pm) w = w * *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + cg0 + 4 * q);
+      }
+      *reinterpret_cast<f32x4 *>(&A[hv * S + 4 * q]) = w;
+    }
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+      const int dz = t / 9, rem = t - dz * 9, dy = rem / 3, dx = rem - dy * 3;
+      const float *ap = A + hbase + ((dz * HY + dy) * HX + dx) * S;
+      const float *wp = W + (size_t)t * a.CK * NCO;
+      for (int q = 0; q < K4; ++q) {
+        const f32x4 av = *reinterpret_cast<const f32x4 *>(ap + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float *wr = wp + (4 * q + j) * NCO;
+#pragma unroll
+          for (int n4 = 0; n4 < NCO; n4 += 4) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + n4);
+            acc[n4 + 0] = fmaf(av[j], wv[0], acc[n4 + 0]);
+            acc[n4 + 1] = fmaf(av[j], wv[1], acc[n4 + 1]);
+            acc[n4 + 2] = fmaf(av[j], wv[2], acc[n4 + 2]);
+            acc[n4 + 3] = fmaf(av[j], wv[3], acc[n4 + 3]);
+          }
+        }
+      }
+    }
+  }
+  // merge the tap groups in order 0, 1, ... and write
+  if (grp > 0) {
+#pragma unroll
+    for (int i = 0; i < NCO; ++i) red[((grp - 1) * TM + m) * NCO + i] = acc[i];
+  }
+  __syncthreads();
+  if (grp == 0 && off >= 0) {
+    for (int g = 1; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < NCO; ++i) acc[i] += red[((g - 1) * TM + m) * NCO + i];
+    float *o = a.out + (size_t)off * a.out_cs;
+#pragma unroll
+    for (int i = 0; i < NCO; ++i)
+      if (i < a.Co) o[i] = acc[i] + a.bias[i];
+  }
+}
+
+bool conv_smalln_ok(const ConvArgs &a, int MB) {
+  const int TM = 32 * MB;
+  return a.ntaps == 27 && a.td == 3 && a.stride == 1 && !a.par && !a.ups && a.bs == 1 && a.Co <= 8 && !a.temb &&
+         !a.resid && !a.stat_part && a.ks <= 1 && a.kt <= 1 && a.out_cs >= a.Co && (TM == 32 || TM == 64 || TM == 128 || TM == 256);
+}
+
+size_t conv_smalln_lds(const ConvArgs &a, int MB) {
+  const int TM = 32 * MB, nco = a.Co <= 4 ? 4 : 8;
+  const size_t HV = (size_t)(a.bz + 2) * (a.by + 2) * (a.bx + 2);
+  return (HV * (a.CK + 4) + (size_t)27 * a.CK * nco + (size_t)(256 / TM) * TM * nco) * sizeof(float);
+}
+
+hipError_t launch_conv_smalln(const ConvArgs &a, int MB, const float *wsm, hipStream_t st) {
+  if (!conv_smalln_ok(a, MB)) return hipErrorInvalidValue;
+  const int TM = 32 * MB;
+  const size_t lds = conv_smalln_lds(a, MB);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)(a.B * a.ntz * a.nty * a.ntx));
+  static bool attr_set[64][2] = {{false}};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int v = a.Co <= 4 ? 0 : 1;
+  if (!attr_set[dev & 63][v]) {
+    hipError_t e = v == 0 ? hipFuncSetAttribute(reinterpret_cast<const void *>(conv_smalln_kernel<4>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                          : hipFuncSetAttribute(reinterpret_cast<const void *>(conv_smalln_kernel<8>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set[dev & 63][v] = true;
+  }
+  if (v == 0) hipLaunchKernelGGL(conv_smalln_kernel<4>, grid, dim3(256), lds, st, a, wsm, TM);
+  else hipLaunchKernelGGL(conv_smalln_kernel<8>, grid, dim3(256), lds, st, a, wsm, TM);
+  return hipGetLastError();
+}
+
+}  // namespace cm

@@ -42,6 +42,8 @@ struct ConvArgs {
   long long wpar_stride;  // floats between the packed weight sets of consecutive parities
   int ks;              // > 1: K is split over gridDim.z workgroups (chunk ranges); each writes its RAW partial
                        //      sums to out + z * kpart (bias / temb / residual / statistics happen in ksplit_combine)
+  int kt;              // > 1 (with the 27-tap register-ring path only): the taps are split as well, kt ranges of
+                       //      27 / kt taps; gridDim.z = ks * kt, partial index = kz * kt + kti
   long long kpart;     // floats between consecutive partial outputs
   int stride;          // 1 or 2
   int ups;             // 1: source is nearest-upsampled x2 on the fly
@@ -69,6 +71,11 @@ int conv_halo_voxels(const ConvArgs &a);
 // MB x NB = number of 32x32 accumulator blocks per wave (workgroup tile 32MB x 32NB).
 hipError_t launch_conv(const ConvArgs &a, int MB, int NB, hipStream_t st);
 bool conv_variant_exists(int MB, int NB);
+// 3x3x3 conv with <= 8 output channels on the vector ALUs (cm_conv_small.hip); weights packed as
+// [chunk][tap][ci in chunk][NCO = 4 or 8] (internal tap order), zero beyond Co.
+bool conv_smalln_ok(const ConvArgs &a, int MB);
+size_t conv_smalln_lds(const ConvArgs &a, int MB);
+hipError_t launch_conv_smalln(const ConvArgs &a, int MB, const float *wsm, hipStream_t st);
 // Persistent, software-pipelined 3x3x3 kernel (cm_conv2.hip): MB x NB accumulator blocks
 // per wave (K split over the 4 waves), grid_x persistent workgroups pulling tiles from
 // ctr (zeroed int[2 * number of N tiles]).

@@ -96,9 +96,11 @@ hipError_t launch_chan_stats(const float *x, int B, int V, int C, int nslice, fl
 // GroupNorm finalisation: nn.GroupNorm(8, C) statistics (biased variance, eps)
 // over the channel-concatenation of up to two tensors (layers.py:30,41,9; unet.py:119)
 // folded with the affine into one scale/shift pair per (sample, channel).
-// grid B, 256 threads.
+// grid B, 1024 threads: a full-resolution tensor arrives as ~100 slots per channel, and the merge
+// of one channel's slots is a serial chain, so the slots are spread over 1024 / Ct lanes and
+// their loads are issued four at a time.
 // --------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ p0, const float *__restrict__ n0,
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float *__restrict__ p0, const float *__restrict__ n0,
                                                           int ns0, int C0, const float *__restrict__ p1,
                                                           const float *__restrict__ n1, int ns1, int C1, int V,
                                                           const float *__restrict__ gamma,
@@ -108,27 +110,36 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
   extern __shared__ float sm[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int Ct = C0 + C1;
-  const int nl = max(1, 256 / Ct);  // slot lanes per channel
+  const int nl = max(1, 1024 / Ct);  // slot lanes per channel
   float *tri = sm;
   float *cmean = sm + (size_t)nl * Ct * 3, *cm2 = cmean + Ct, *gmean = cm2 + Ct, *grstd = gmean + groups;
   // stage 1: thread (channel c, lane j) merges the slots j, j+nl, ... of its channel in order
-  for (int idx = tid; idx < nl * Ct; idx += 256) {
+  for (int idx = tid; idx < nl * Ct; idx += 1024) {
     const int c = idx % Ct, j = idx / Ct;
     const float *p, *nn;
     int Cx, cc, ns;
     if (c < C0) { p = p0; nn = n0; Cx = C0; cc = c; ns = ns0; } else { p = p1; nn = n1; Cx = C1; cc = c - C0; ns = ns1; }
     float N = 0.f, M = 0.f, S2 = 0.f;
-    for (int s = j; s < ns; s += nl) {
-      const float cnt = nn[(size_t)b * ns + s];
-      const float *q = p + (((size_t)b * ns + s) * Cx + cc) * 2;
-      chan_combine(N, M, S2, cnt, q[0], q[1]);
+    for (int s0 = j; s0 < ns; s0 += 4 * nl) {
+      float cnt[4];
+      float2 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = s0 + u * nl;
+        const int sc = s < ns ? s : j;
+        cnt[u] = s < ns ? nn[(size_t)b * ns + sc] : 0.f;
+        q[u] = *reinterpret_cast<const float2 *>(p + (((size_t)b * ns + sc) * Cx + cc) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u * nl < ns) chan_combine(N, M, S2, cnt[u], q[u].x, q[u].y);
     }
     tri[(j * Ct + c) * 3 + 0] = N;
     tri[(j * Ct + c) * 3 + 1] = M;
     tri[(j * Ct + c) * 3 + 2] = S2;
   }
   __syncthreads();
-  for (int c = tid; c < Ct; c += 256) {
+  for (int c = tid; c < Ct; c += 1024) {
     float N = 0.f, M = 0.f, S2 = 0.f;
     for (int j = 0; j < nl; ++j) chan_combine(N, M, S2, tri[(j * Ct + c) * 3], tri[(j * Ct + c) * 3 + 1], tri[(j * Ct + c) * 3 + 2]);
     cmean[c] = M;
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
     grstd[tid] = rsqrtf(S2 / N + eps);
   }
   __syncthreads();
-  for (int c = tid; c < Ct; c += 256) {
+  for (int c = tid; c < Ct; c += 1024) {
     const int g = c / cg;
     const float sc = grstd[g] * gamma[c];
     gn[((size_t)b * 2 + 0) * Ct + c] = sc;
@@ -160,9 +171,9 @@ hipError_t launch_gn_finalize(const float *part0, const float *cnt0, int ns0, in
                               int groups, float eps, float *gn, float *mr, int B, hipStream_t st) {
   const int Ct = C0 + C1;
   if (Ct % groups != 0) return hipErrorInvalidValue;
-  const int nl = 256 / Ct > 0 ? 256 / Ct : 1;
+  const int nl = 1024 / Ct > 0 ? 1024 / Ct : 1;
   const size_t smem = ((size_t)nl * Ct * 3 + 2 * Ct + 2 * groups) * sizeof(float);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), smem, st, part0, cnt0, ns0, C0, part1, cnt1, ns1, C1, V,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(1024), smem, st, part0, cnt0, ns0, C0, part1, cnt1, ns1, C1, V,
                      gamma, beta, groups, eps, gn, mr);
   return hipGetLastError();
 }
@@ -171,52 +182,64 @@ hipError_t launch_gn_finalize(const float *part0, const float *cnt0, int ns0, in
 // Second pass of a K-split convolution (tiny-spatial layers, cm_conv.hip ks > 1): sums the
 // S raw partial outputs in a fixed order, applies the conv epilogue (bias, time-embedding
 // row, residual) and produces the GroupNorm statistics of the result per 32-row slot.
-// grid (nslots, B), 256 threads = C channels x (256/C) row lanes; C <= 256.
+// grid (nslots, B), 1024 threads = C channels x (1024/C) row lanes; C <= 256, so a thread owns at
+// most 8 of the slot's 32 rows and keeps all their partial loads in flight together.
 // --------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ksplit_combine_kernel(const CombineArgs a) {
-  __shared__ float red[256];
+__global__ __launch_bounds__(1024) void ksplit_combine_kernel(const CombineArgs a) {
+  __shared__ float red[1024];
   const int slot = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const int nl = 256 / a.C > 0 ? 256 / a.C : 1;
+  const int nl = 1024 / a.C;                 // row lanes (>= 4)
   const int c = tid % a.C, rl = tid / a.C;
   const bool act = rl < nl;
   const int r0 = slot * 32, r1 = min(a.V, r0 + 32);
+  const float *__restrict__ part = a.part;
+  const float *__restrict__ resid = a.resid;
   float add = 0.f;
   if (act) {
     add = a.bias[c];
     if (a.temb) add += a.temb[(size_t)a.tidx[b] * a.temb_stride + c];
   }
-  float vals[32];
-  float s1 = 0.f, cnt = 0.f;
+  constexpr int RPT = 8;                     // rows per thread (32 / nl <= 8)
+  float vals[RPT];
+  size_t idx[RPT];
+  bool ok[RPT];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
+  for (int i = 0; i < RPT; ++i) {
     const int row = r0 + rl + i * nl;
+    ok[i] = act && i * nl < 32 && row < r1;
+    idx[i] = ok[i] ? ((size_t)b * a.V + row) * a.C + c : 0;
     vals[i] = 0.f;
-    if (act && i * nl < 32 && row < r1) {
-      const size_t idx = ((size_t)b * a.V + row) * a.C + c;
-      float v = 0.f;
-      for (int s = 0; s < a.S; ++s) v += a.part[(size_t)s * a.stride + idx];
-      v += add;
-      if (a.resid) v += a.resid[((size_t)b * a.V + row) * a.res_cs + c];
-      a.out[idx] = v;
-      vals[i] = v;
-      s1 += v;
-      cnt += 1.f;
-    }
+  }
+  // partial sums in the fixed order s = 0..S-1; the loads of one s for all rows go out together
+  for (int s = 0; s < a.S; ++s) {
+    float p[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) p[i] = part[(size_t)s * a.stride + idx[i]];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) vals[i] += p[i];
+  }
+  float rs[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) rs[i] = (resid && ok[i]) ? resid[(idx[i] / a.C) * a.res_cs + c] : 0.f;
+  float s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    vals[i] = ok[i] ? vals[i] + add + rs[i] : 0.f;
+    if (ok[i]) { a.out[idx[i]] = vals[i]; s1 += vals[i]; }
   }
   if (!a.stat_part) return;
   // per-channel statistics of the slot: merge the row lanes through LDS (fixed order)
   red[tid] = s1;
   __syncthreads();
   float tot = 0.f;
-  for (int l = 0; l < nl; ++l) tot += red[l * a.C + c];
+  if (act)
+    for (int l = 0; l < nl; ++l) tot += red[l * a.C + c];
   const float n = (float)(r1 - r0);
   const float mean = tot / n;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const int row = r0 + rl + i * nl;
-    if (act && i * nl < 32 && row < r1) { const float d = vals[i] - mean; q += d * d; }
-  }
+  for (int i = 0; i < RPT; ++i)
+    if (ok[i]) { const float d = vals[i] - mean; q += d * d; }
   __syncthreads();
   red[tid] = q;
   __syncthreads();
@@ -232,7 +255,7 @@ __global__ __launch_bounds__(256) void ksplit_combine_kernel(const CombineArgs a
 
 hipError_t launch_ksplit_combine(const CombineArgs &a, hipStream_t st) {
   if (a.C > 256 || a.C < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ksplit_combine_kernel, dim3(a.nslots, a.B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ksplit_combine_kernel, dim3(a.nslots, a.B), dim3(1024), 0, st, a);
   return hipGetLastError();
 }
 

@@ -98,6 +98,10 @@ struct Op {
   int gn_op = -1;           // index of the OP_GNFIN op that produced this conv's on-load normalisation
   int ref_taps = 1;         // taps of the reference weight (27 even when the forward runs the 8-tap parity form)
   int ks = 1;               // K split over workgroups (tiny-spatial layers) + combine pass
+  int kt = 1;               // ... and split of the 27 taps on top (ks * kt partial outputs)
+  bool small_n = false;     // <= 8 output channels: vector-ALU kernel (cm_conv_small.hip)
+  float *d_wsmall = nullptr;
+  int small_nco = 4;
   float *d_zero_bias = nullptr;
   const Act *out_act = nullptr, *resid_act = nullptr;
   bool v2 = false;      // persistent pipelined kernel (cm_conv2.hip)
@@ -107,6 +111,7 @@ struct Op {
   std::string label;
   double prof_ms = 0;
   int64_t prof_n = 0;
+  int prof_B = 0;           // batch of the last launch (profile report)
   // stats
   const Act *act = nullptr;
   // gn finalize
@@ -403,7 +408,7 @@ void pick_tile(Op &op, int B) {
   double best = -1;
   int bbs = 1, bbz = 1, bby = 1, bbx = 1, bMB = 1;
   const int ntn = (a.Co + 32 * NB - 1) / (32 * NB);
-  const int max_bs = (vox <= 64 && !op.stat_act) ? 4 : 1;  // fused statistics need one sample per tile
+  const int max_bs = (vox <= 64 && !op.stat_act && !op.small_n) ? 4 : 1;  // fused statistics need one sample per tile
   for (int bs = 1; bs <= max_bs; ++bs)
     for (int bz = 1; bz <= Zo; ++bz)
       for (int by = 1; by <= Yo; ++by)
@@ -411,6 +416,7 @@ void pick_tile(Op &op, int B) {
           const int nbox = bs * bz * by * bx;
           const int MB = (nbox + 31) / 32;
           if (MB > max_blk) continue;
+          if (op.small_n && (MB & (MB - 1))) continue;  // its thread groups need 256 % (32 MB) == 0
           if (force_mb && MB != force_mb && vox >= 128) continue;
           a.bs = bs; a.bz = bz; a.by = by; a.bx = bx;
           const size_t lds = cm::conv_lds_bytes(a, MB, NB);
@@ -533,6 +539,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   // (all 128 output channels per workgroup, K split over workgroups) amortise the per-workgroup
   // fixed costs over 4x the matrix work
   if (s.ntaps == 27 && s.out->V() <= 64 && s.Co % 128 == 0 && !getenv("CM_NO_FAT_TILES")) op.NB = 4;
+  if (s.ntaps == 27 && s.out->V() <= 64 && getenv("CM_QR_NB")) op.NB = atoi(getenv("CM_QR_NB"));
   if (op.v2) {
     if (dev_alloc(m, (void **)&op.d_ctr, 64 * sizeof(int))) return 1;
     CM_HIP(hipMemset(op.d_ctr, 0, 64 * sizeof(int)));
@@ -555,6 +562,22 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     }
   } else {
     wf = pack_conv_weights(wi.data(), (int)w.shape[0], Ci_ref, s.ntaps, Ci_pad, a.CK, op.NB);
+  }
+  // the UNet's last conv (base -> C channels): vector-ALU kernel instead of a 32-wide MFMA tile
+  if (s.ntaps == 27 && s.stride == 1 && !s.ups && s.Co <= 8 && !s.stats && !s.temb && !s.resid && !op.v2 &&
+      !getenv("CM_NO_SMALLN")) {
+    op.small_n = true;
+    op.small_nco = s.Co <= 4 ? 4 : 8;
+    const int nco = op.small_nco, nch = Ci_pad / a.CK;
+    std::vector<float> ws((size_t)nch * 27 * a.CK * nco, 0.f);
+    for (int ch = 0; ch < nch; ++ch)
+      for (int t = 0; t < 27; ++t)
+        for (int ci = 0; ci < a.CK; ++ci)
+          for (int co = 0; co < s.Co; ++co) {
+            const int cig = ch * a.CK + ci;
+            if (cig < Ci_ref) ws[(((size_t)ch * 27 + t) * a.CK + ci) * nco + co] = wi[((size_t)co * Ci_ref + cig) * 27 + t];
+          }
+    if (upload(m, ws, &op.d_wsmall)) return 1;
   }
   float *dw = nullptr, *db = nullptr;
   if (upload(m, wf, &dw)) return 1;
@@ -580,8 +603,13 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   const int nchunks = a.nch0 + a.nch1;
   if (s.ntaps == 27 && !parity && a.CK == 32 && nchunks >= 2 && s.out->V() <= 64 && s.Co <= 256 && s.Co == s.out->C &&
       op.stat_act && !getenv("CM_NO_KSPLIT")) {
-    op.ks = std::min(nchunks, 4);
-    const size_t need = (size_t)op.ks * m->cfg.max_batch * s.out->V() * s.Co;
+    static const int qr_ks = getenv("CM_QR_KS") ? atoi(getenv("CM_QR_KS")) : 4;
+    // (splitting the taps as well -- CM_QR_KT=3 -- was measured slower: each extra workgroup repeats the
+    // fixed setup / staging / epilogue phases, which is what bounds these layers, profiles/round1_notes.md)
+    static const int qr_kt = getenv("CM_QR_KT") ? atoi(getenv("CM_QR_KT")) : 1;
+    op.ks = std::max(1, std::min(nchunks, qr_ks));
+    op.kt = (qr_kt == 3 || qr_kt == 9) ? qr_kt : 1;
+    const size_t need = (size_t)op.ks * op.kt * m->cfg.max_batch * s.out->V() * s.Co;
     m->ks_scratch_floats = std::max(m->ks_scratch_floats, need);
     std::vector<float> zb((size_t)co_pad, 0.f);
     if (upload(m, zb, &op.d_zero_bias)) return 1;
@@ -839,6 +867,7 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
         }
         cm::ConvArgs ca = op.ca;
         ca.B = B;
+        op.prof_B = B;
         ca.nts = (B + ca.bs - 1) / ca.bs;
         const size_t Vs = (size_t)ca.Zs * ca.Ys * ca.Xs, Vo = (size_t)ca.Zo * ca.Yo * ca.Xo;
         ca.src0 += (size_t)b0 * Vs * ca.C0;
@@ -865,16 +894,16 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
           ca.stat_cnt = op.stat_act->cnt + (size_t)b0 * ns;
           op.stat_act->nslots = ns;
         }
-        if (op.ks > 1) {
+        if (op.ks * op.kt > 1) {
           cm::ConvArgs ka = ca;
           const int V = op.out_act->V();
           float *scratch = m->ks_scratch + (size_t)slab * m->ks_scratch_floats;
           ka.temb = nullptr; ka.resid = nullptr; ka.stat_part = nullptr; ka.bias = op.d_zero_bias;
           ka.out = scratch; ka.out_cs = ka.Co;
-          ka.ks = op.ks; ka.kpart = (long long)B * V * ka.Co;
+          ka.ks = op.ks; ka.kt = op.kt; ka.kpart = (long long)B * V * ka.Co;
           CM_HIP(cm::launch_conv(ka, op.MB, op.NB, st));
           cm::CombineArgs cb{};
-          cb.part = scratch; cb.S = op.ks; cb.stride = ka.kpart;
+          cb.part = scratch; cb.S = op.ks * op.kt; cb.stride = ka.kpart;
           cb.bias = ca.bias; cb.temb = ca.temb; cb.temb_stride = ca.temb_stride; cb.tidx = ca.tidx;
           cb.resid = ca.resid; cb.res_cs = ca.res_cs;
           cb.out = ca.out; cb.C = ka.Co; cb.V = V; cb.B = B;
@@ -883,6 +912,8 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
           cb.stat_cnt = op.stat_act->cnt + (size_t)b0 * cb.nslots;
           op.stat_act->nslots = cb.nslots;
           CM_HIP(cm::launch_ksplit_combine(cb, st));
+        } else if (op.small_n) {
+          CM_HIP(cm::launch_conv_smalln(ca, op.MB, op.d_wsmall, st));
         } else if (op.v2) {
           const long tiles = (long)ca.ntz * ca.nty * ca.ntx * B;
           const int gx = (int)std::min<long>(tiles, op.grid_x);
@@ -1498,8 +1529,9 @@ int cm_profile_report(cm_model *m, char *buf, int64_t capacity) {
     const double us = op.prof_ms * 1e3 / op.prof_n;
     if (op.kind == OP_CONV) {
       const cm::ConvArgs &a = op.ca;
-      const double tf = op.flops_per_sample * a.B / (us * 1e-6) / 1e12;
-      snprintf(line, sizeof(line), "%-52s %9.1f us %7.2f TF  %s%d NB%d box %dx%dx%dx%d grid %dx%d CK%d lds %zu\n", op.label.c_str(), us, tf,
+      const double tf = op.flops_per_sample * op.prof_B / (us * 1e-6) / 1e12;
+      snprintf(line, sizeof(line), "%-52s %9.1f us %7.2f TF %8.1f MF/sample B%d ks%d  %s%d NB%d box %dx%dx%dx%d grid %dx%d CK%d lds %zu\n", op.label.c_str(), us, tf,
+               op.flops_per_sample / 1e6, op.prof_B, op.ks,
                op.v2 ? "v2 MB" : "MB", op.MB, op.NB, a.bs, a.bz, a.by, a.bx, op.v2 ? op.grid_x : a.nts * a.ntz * a.nty * a.ntx,
                (a.Co + 32 * op.NB - 1) / (32 * op.NB), a.CK, op.v2 ? cm::conv2_lds_bytes(a, op.MB, op.NB) : cm::conv_lds_bytes(a, op.MB, op.NB));
     } else {
