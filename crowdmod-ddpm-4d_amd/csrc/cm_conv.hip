@@ -358,6 +358,45 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     }
   }
 
+  if constexpr (FAST == 27) {
+    if (a.s2w && kz == 0 && kti == 0) {
+      // ---- fused 1x1x1 skip convolution: K chunks over the raw block input, centre tap ----
+      const int n2a = a.s2C0 >> 5, n2 = (a.s2C0 + a.s2C1) >> 5;
+      const f32x4 *w2 = reinterpret_cast<const f32x4 *>(a.s2w) + (size_t)nt * n2 * 4 * NB * 64 + lane;
+      const int q8 = tid & 7;
+      for (int c2 = 0; c2 < n2; ++c2) {
+        const float *src2;
+        int Cs2, c02;
+        if (c2 < n2a) { src2 = a.s2src0; Cs2 = a.s2C0; c02 = c2 * 32; }
+        else { src2 = a.s2src1; Cs2 = a.s2C1; c02 = (c2 - n2a) * 32; }
+        f32x4 wq[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) wq[nb] = w2[((size_t)c2 * 4 + wave) * NB * 64 + nb * 64];
+        __syncthreads();  // previous consumer of the A region is done
+        f32x4 sv[MB];
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+          const int off = outoff[(tid >> 3) + 32 * k];
+          sv[k] = *reinterpret_cast<const f32x4 *>(src2 + (size_t)(off >= 0 ? off : 0) * Cs2 + c02 + 4 * q8);
+          if (off < 0) sv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < MB; ++k) *reinterpret_cast<f32x4 *>(&A[((tid >> 3) + 32 * k) * S + 4 * q8]) = sv[k];
+        __syncthreads();
+        f32x4 af2[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) af2[mb] = *reinterpret_cast<const f32x4 *>(&A[(mb * 32 + r) * S + wave * 8 + 4 * h]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af2[mb][jj], wq[nb][jj], acc[mb][nb], 0, 0, 0);
+      }
+    }
+  }
+
   CM_RT(3)
   // ---- cross-wave reduction (rounds of RB blocks) + epilogue -------------------
   if (a.dbg & 4) {

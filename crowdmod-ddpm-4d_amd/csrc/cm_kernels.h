@@ -59,6 +59,12 @@ struct ConvArgs {
   float *stat_part;
   float *stat_cnt;
   int stat_C, stat_ns;
+  // fused 1x1x1 skip path (ResnetBlock.match_input, layers.py:46,74) of a stride-1 27-tap conv on
+  // the register-ring path: extra K chunks of 32 channels read from the RAW block input (no
+  // normalisation), centre tap only; s2w packed like wfrag with ntaps = 1, CK = 32
+  const float *s2src0; const float *s2src1;
+  int s2C0, s2C1;
+  const float *s2w;
   int dbg;             // ablation switches for performance studies (0 in production)
   float *dbg_buf;      // cycle-stamp sink of the diagnostic build paths
   int stagger;         // start delay (in 64-cycle units) applied to every other first-wave workgroup

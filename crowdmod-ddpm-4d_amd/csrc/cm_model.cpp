@@ -99,6 +99,11 @@ struct Op {
   int ref_taps = 1;         // taps of the reference weight (27 even when the forward runs the 8-tap parity form)
   int ks = 1;               // K split over workgroups (tiny-spatial layers) + combine pass
   int kt = 1;               // ... and split of the 27 taps on top (ks * kt partial outputs)
+  // inference-time fusion of the block's 1x1x1 skip conv into conv_2 (see ConvArgs::s2w)
+  const Act *skip0 = nullptr, *skip1 = nullptr;
+  std::string skip_w, skip_b;
+  float *d_s2w = nullptr, *d_bias_fused = nullptr;
+  bool skip_if_fused = false;  // this op is the stand-alone skip conv that a later op absorbs
   bool small_n = false;     // <= 8 output channels: vector-ALU kernel (cm_conv_small.hip)
   float *d_wsmall = nullptr;
   int small_nco = 4;
@@ -502,6 +507,8 @@ struct ConvSpec {
   int ci_valid = -1;  // valid input channels of the reference weight (first conv: 3 of 8)
   bool stats = false; // produce the GroupNorm statistics of `out` in the epilogue
   int pm_off = -1;    // Dropout3d mask slice of the input (conv_2 of a ResnetBlock)
+  const Act *skip0 = nullptr, *skip1 = nullptr;  // block input whose match_input conv may be fused in
+  std::string skip_w, skip_b;
 };
 
 int add_conv(cm_model *m, const ConvSpec &s) {
@@ -614,6 +621,21 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     std::vector<float> zb((size_t)co_pad, 0.f);
     if (upload(m, zb, &op.d_zero_bias)) return 1;
   }
+  // fuse the 1x1x1 skip conv when this conv runs on the 27-tap register-ring path without K split
+  if (s.skip0 && s.ntaps == 27 && !parity && a.CK == 32 && op.ks * op.kt == 1 && !op.v2 && !op.small_n && s.stride == 1 &&
+      s.skip0->C % 32 == 0 && (!s.skip1 || s.skip1->C % 32 == 0) && !getenv("CM_NO_FUSE_SKIP")) {
+    const Param &w2 = P(m, s.skip_w);
+    const Param &b2 = P(m, s.skip_b);
+    const int Ci2 = (int)w2.shape[1];
+    if (Ci2 == s.skip0->C + (s.skip1 ? s.skip1->C : 0) && (int)w2.shape[0] == s.Co) {
+      std::vector<float> w2f = pack_conv_weights(w2.host.data(), s.Co, Ci2, 1, Ci2, 32, op.NB);
+      if (upload(m, w2f, &op.d_s2w)) return 1;
+      std::vector<float> bf((size_t)co_pad, 0.f);
+      for (int i = 0; i < s.Co; ++i) bf[i] = b.host[i] + b2.host[i];
+      if (upload(m, bf, &op.d_bias_fused)) return 1;
+      op.skip0 = s.skip0; op.skip1 = s.skip1; op.skip_w = s.skip_w; op.skip_b = s.skip_b;
+    }
+  }
   op.flops_per_sample = 2.0 * s.out->V() * s.Co * (double)Ci_ref * s.ntaps;
   op.label = s.wname;
   m->ops.push_back(op);
@@ -691,12 +713,14 @@ int build_ops(cm_model *m) {
     add_stats(m, h1);
     if (add_gnfin(m, h1, nullptr, p + ".normalize_2.weight", p + ".normalize_2.bias", &gn2)) return 1;
     const Act *resid = x0;
+    int mi_index = -1;
     if (b.cin != b.cout) {
       Act *r = new_act(m, p + ".match_input", b.cout, Zl[l], Yl[l], Xl[l], false, &rc);
       if (rc) return 1;
       ConvSpec cs; cs.s0 = x0; cs.s1 = x1; cs.ntaps = 1; cs.wname = p + ".match_input.weight"; cs.bname = p + ".match_input.bias";
       cs.out = r; cs.Co = b.cout;
       if (add_conv(m, cs)) return 1;
+      mi_index = (int)m->ops.size() - 1;
       resid = r;
     } else if (x1) {
       return fail("identity skip with concatenated input is not expressible (block %s)", p.c_str());
@@ -705,7 +729,9 @@ int build_ops(cm_model *m) {
     if (rc) return 1;
     ConvSpec c2; c2.s0 = h1; c2.gn = gn2; c2.silu = 1; c2.wname = p + ".conv_2.weight"; c2.bname = p + ".conv_2.bias";
     c2.resid = resid; c2.out = h2; c2.Co = b.cout; c2.stats = true; c2.pm_off = temb_off[p];
+    if (mi_index >= 0) { c2.skip0 = x0; c2.skip1 = x1; c2.skip_w = p + ".match_input.weight"; c2.skip_b = p + ".match_input.bias"; }
     if (add_conv(m, c2)) return 1;
+    if (mi_index >= 0 && m->ops.back().d_s2w) m->ops[mi_index].skip_if_fused = true;
     add_stats(m, h2);
     *result = h2;
     if (b.attention) {
@@ -848,6 +874,7 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
     }
     switch (op.kind) {
       case OP_CONV: {
+        if (op.skip_if_fused && !m->train_fwd) break;  // absorbed by the block's conv_2 (inference plan)
         if (op.tuned_B < 0) {
           if (op.v2) pick_tile2(op, TUNE_BATCH);
           else pick_tile(op, TUNE_BATCH);
@@ -883,6 +910,14 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
           ca.tidx = m->train_iota + b0;
         }
         if (ca.resid) ca.resid += (size_t)b0 * Vo * ca.res_cs;
+        if (op.d_s2w && !m->train_fwd) {
+          if (32 * op.MB > cm::conv_halo_voxels(ca)) return fail("fused skip conv: tile rows exceed the staged box");
+          ca.s2w = op.d_s2w;
+          ca.s2src0 = op.skip0->d + (size_t)b0 * Vo * op.skip0->C; ca.s2C0 = op.skip0->C;
+          ca.s2src1 = op.skip1 ? op.skip1->d + (size_t)b0 * Vo * op.skip1->C : nullptr; ca.s2C1 = op.skip1 ? op.skip1->C : 0;
+          ca.resid = nullptr;
+          ca.bias = op.d_bias_fused;
+        }
         ca.out += (size_t)b0 * Vo * ca.out_cs;
         int ns = 0;
         if (op.stat_act) {
