@@ -34,7 +34,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division sequence
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-// FAST = 0: generic step loop; 27 / 8: CK == 32 with that many taps (register weight ring)
+// FAST = 0: generic step loop; 27 / 8: CK == 32 with that many taps (register weight ring);
+// 127: the 27-tap ring path plus the fused 1x1x1 skip chunks (its own variant so that the plain
+// kernels do not carry its registers)
 template <int MB, int NB, int FAST>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -137,27 +139,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   const int Ctot = a.C0 + a.C1;
   const f32x4 *wtile = reinterpret_cast<const f32x4 *>(a.wfrag + (size_t)par * a.wpar_stride) +
                        (size_t)nt * nchunks * nsteps * NB * 64 + lane;
-  // K split over workgroups (tiny-spatial layers): this one owns chunks [ch0, ch1) and, on the
-  // register-ring path, the tap range [tb, te) (kt ranges of TAPS / kt taps, a multiple of PD)
-  const int ktn = a.kt > 1 ? a.kt : 1;
-  const int ksplit = (a.ks > 1 || ktn > 1) ? 1 : 0;
-  const int kz = ksplit ? (int)blockIdx.z / ktn : 0;
-  const int kti = ksplit ? (int)blockIdx.z % ktn : 0;
+  // K split over workgroups (tiny-spatial layers): this one owns chunks [ch0, ch1).
+  // (Splitting the taps as well was tried and measured slower -- every extra workgroup repeats the
+  // fixed setup / staging / epilogue phases that bound those layers -- and made the tap loop bounds
+  // dynamic, which cost registers in every variant; see profiles/round1_notes.md.)
+  const int kz = (a.ks > 1) ? (int)blockIdx.z : 0;
   const int ch0 = (a.ks > 1) ? kz * nchunks / a.ks : 0;
   const int ch1 = (a.ks > 1) ? (kz + 1) * nchunks / a.ks : nchunks;
-  float *const outp = a.out + (size_t)(ksplit ? blockIdx.z : 0) * a.kpart;
+  float *const outp = a.out + (size_t)kz * a.kpart;
 
   const int q4 = tid % K4, v0 = tid / K4, vstep = 256 / K4;
 
   constexpr bool fast = FAST != 0;           // host guarantees CK == 32 && ntaps == FAST
-  constexpr int TAPS = FAST ? FAST : 27;
+  constexpr int TAPS = FAST ? FAST % 100 : 27;
   constexpr int PD = (TAPS == 27) ? CM_PD27 : CM_PD8;   // weight prefetch depth of the fast path (taps), TAPS % PD == 0
-  const int tb = fast ? kti * (TAPS / ktn) : 0, te = fast ? tb + TAPS / ktn : TAPS;
   f32x4 bq[PD][NB];
   if constexpr (fast) {
 #pragma unroll
     for (int d = 0; d < PD; ++d) {
-      const f32x4 *wp = wtile + ((size_t)ch0 * (TAPS * 4) + (wave + 4 * (tb + d))) * NB * 64;
+      const f32x4 *wp = wtile + ((size_t)ch0 * (TAPS * 4) + (wave + 4 * d)) * NB * 64;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) bq[d][nb] = wp[nb * 64];
     }
@@ -295,16 +295,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       };
       f32x4 afn[MB];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) afn[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + tap_off(tb)]);
+      for (int mb = 0; mb < MB; ++mb) afn[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + tap_off(0)]);
 #pragma unroll 1
-      for (int i0 = tb; i0 < te; i0 += PD) {
+      for (int i0 = 0; i0 < TAPS; i0 += PD) {
 #pragma unroll
         for (int d = 0; d < PD; ++d) {
           const int t = i0 + d;  // tap index
           f32x4 af[MB];
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) af[mb] = afn[mb];
-          const int aoffn = tap_off(t + 1 < te ? t + 1 : t);  // (the last tap re-reads itself)
+          const int aoffn = tap_off(t + 1 < TAPS ? t + 1 : t);  // (the last tap re-reads itself)
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) afn[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + aoffn]);
 #pragma unroll
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mb][jj], bq[d][nb][jj], acc[mb][nb], 0, 0, 0);
           // refill this ring slot with the fragments PD taps ahead (possibly next chunk)
           int tn = t + PD, chn = ch;
-          if (tn >= te) { tn -= te - tb; chn += 1; }
+          if (tn >= TAPS) { tn -= TAPS; chn += 1; }
           if (chn < ch1) {
             const f32x4 *wp = (a.dbg & 64) ? wtile : wtile + ((size_t)chn * (TAPS * 4) + (wave + 4 * tn)) * NB * 64;
 #pragma unroll
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     }
   }
 
-  if constexpr (FAST == 27) {
-    if (a.s2w && kz == 0 && kti == 0) {
+  if constexpr (FAST == 127) {
+    if (a.s2w && kz == 0) {
       // ---- fused 1x1x1 skip convolution: K chunks over the raw block input, centre tap ----
       const int n2a = a.s2C0 >> 5, n2 = (a.s2C0 + a.s2C1) >> 5;
       const f32x4 *w2 = reinterpret_cast<const f32x4 *>(a.s2w) + (size_t)nt * n2 * 4 * NB * 64 + lane;
@@ -599,10 +599,9 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
   const size_t lds = conv_lds_bytes(a, MB, NB);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int TN = 32 * NB;
-  if (a.par && (a.ks > 1 || a.kt > 1)) return hipErrorInvalidValue;
-  if (a.kt > 1 && !(a.CK == 32 && a.ntaps == 27 && 27 % a.kt == 0 && (27 / a.kt) % CM_PD27 == 0)) return hipErrorInvalidValue;
+  if (a.par && a.ks > 1) return hipErrorInvalidValue;
   dim3 grid((unsigned)(a.nts * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + TN - 1) / TN),
-            a.par ? 8u : (unsigned)((a.ks > 1 ? a.ks : 1) * (a.kt > 1 ? a.kt : 1)));
+            a.par ? 8u : (a.ks > 1 ? (unsigned)a.ks : 1u));
   const int fastk = (a.CK == 32 && (a.ntaps == 27 || a.ntaps == 8)) ? a.ntaps : 0;
 #define CM_LAUNCH(m, n, f)                                                                       \
   {                                                                                              \
@@ -621,6 +620,7 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
   }
 #define X(m, n)                                    \
   if (MB == m && NB == n) {                        \
+    if (fastk == 27 && a.s2w) CM_LAUNCH(m, n, 127) \
     if (fastk == 27) CM_LAUNCH(m, n, 27)           \
     if (fastk == 8) CM_LAUNCH(m, n, 8)             \
     CM_LAUNCH(m, n, 0)                             \

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvArgs a, cons
 bool conv_smalln_ok(const ConvArgs &a, int MB) {
   const int TM = 32 * MB;
   return a.ntaps == 27 && a.td == 3 && a.stride == 1 && !a.par && !a.ups && a.bs == 1 && a.Co <= 8 && !a.temb &&
-         !a.resid && !a.stat_part && a.ks <= 1 && a.kt <= 1 && a.out_cs >= a.Co && (TM == 32 || TM == 64 || TM == 128 || TM == 256);
+         !a.resid && !a.stat_part && a.ks <= 1 && a.out_cs >= a.Co && (TM == 32 || TM == 64 || TM == 128 || TM == 256);
 }
 
 size_t conv_smalln_lds(const ConvArgs &a, int MB) {

@@ -42,8 +42,6 @@ struct ConvArgs {
   long long wpar_stride;  // floats between the packed weight sets of consecutive parities
   int ks;              // > 1: K is split over gridDim.z workgroups (chunk ranges); each writes its RAW partial
                        //      sums to out + z * kpart (bias / temb / residual / statistics happen in ksplit_combine)
-  int kt;              // > 1 (with the 27-tap register-ring path only): the taps are split as well, kt ranges of
-                       //      27 / kt taps; gridDim.z = ks * kt, partial index = kz * kt + kti
   long long kpart;     // floats between consecutive partial outputs
   int stride;          // 1 or 2
   int ups;             // 1: source is nearest-upsampled x2 on the fly

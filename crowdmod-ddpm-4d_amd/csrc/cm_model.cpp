@@ -98,7 +98,6 @@ struct Op {
   int gn_op = -1;           // index of the OP_GNFIN op that produced this conv's on-load normalisation
   int ref_taps = 1;         // taps of the reference weight (27 even when the forward runs the 8-tap parity form)
   int ks = 1;               // K split over workgroups (tiny-spatial layers) + combine pass
-  int kt = 1;               // ... and split of the 27 taps on top (ks * kt partial outputs)
   // inference-time fusion of the block's 1x1x1 skip conv into conv_2 (see ConvArgs::s2w)
   const Act *skip0 = nullptr, *skip1 = nullptr;
   std::string skip_w, skip_b;
@@ -545,7 +544,9 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   // tiny-spatial layers are overhead-bound, not throughput-bound: fewer, fatter workgroups
   // (all 128 output channels per workgroup, K split over workgroups) amortise the per-workgroup
   // fixed costs over 4x the matrix work
-  if (s.ntaps == 27 && s.out->V() <= 64 && s.Co % 128 == 0 && !getenv("CM_NO_FAT_TILES")) op.NB = 4;
+  // (NB = 4 "fat" tiles -- all 128 output channels per workgroup -- spill ~80 VGPRs on the register-ring path and
+  // measured no better than two NB = 2 workgroups: opt-in only)
+  if (s.ntaps == 27 && s.out->V() <= 64 && s.Co % 128 == 0 && getenv("CM_FAT_TILES")) op.NB = 4;
   if (s.ntaps == 27 && s.out->V() <= 64 && getenv("CM_QR_NB")) op.NB = atoi(getenv("CM_QR_NB"));
   if (op.v2) {
     if (dev_alloc(m, (void **)&op.d_ctr, 64 * sizeof(int))) return 1;
@@ -611,18 +612,14 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   if (s.ntaps == 27 && !parity && a.CK == 32 && nchunks >= 2 && s.out->V() <= 64 && s.Co <= 256 && s.Co == s.out->C &&
       op.stat_act && !getenv("CM_NO_KSPLIT")) {
     static const int qr_ks = getenv("CM_QR_KS") ? atoi(getenv("CM_QR_KS")) : 4;
-    // (splitting the taps as well -- CM_QR_KT=3 -- was measured slower: each extra workgroup repeats the
-    // fixed setup / staging / epilogue phases, which is what bounds these layers, profiles/round1_notes.md)
-    static const int qr_kt = getenv("CM_QR_KT") ? atoi(getenv("CM_QR_KT")) : 1;
     op.ks = std::max(1, std::min(nchunks, qr_ks));
-    op.kt = (qr_kt == 3 || qr_kt == 9) ? qr_kt : 1;
-    const size_t need = (size_t)op.ks * op.kt * m->cfg.max_batch * s.out->V() * s.Co;
+    const size_t need = (size_t)op.ks * m->cfg.max_batch * s.out->V() * s.Co;
     m->ks_scratch_floats = std::max(m->ks_scratch_floats, need);
     std::vector<float> zb((size_t)co_pad, 0.f);
     if (upload(m, zb, &op.d_zero_bias)) return 1;
   }
   // fuse the 1x1x1 skip conv when this conv runs on the 27-tap register-ring path without K split
-  if (s.skip0 && s.ntaps == 27 && !parity && a.CK == 32 && op.ks * op.kt == 1 && !op.v2 && !op.small_n && s.stride == 1 &&
+  if (s.skip0 && s.ntaps == 27 && !parity && a.CK == 32 && !op.v2 && !op.small_n && s.stride == 1 &&
       s.skip0->C % 32 == 0 && (!s.skip1 || s.skip1->C % 32 == 0) && !getenv("CM_NO_FUSE_SKIP")) {
     const Param &w2 = P(m, s.skip_w);
     const Param &b2 = P(m, s.skip_b);
@@ -929,16 +926,16 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
           ca.stat_cnt = op.stat_act->cnt + (size_t)b0 * ns;
           op.stat_act->nslots = ns;
         }
-        if (op.ks * op.kt > 1) {
+        if (op.ks > 1) {
           cm::ConvArgs ka = ca;
           const int V = op.out_act->V();
           float *scratch = m->ks_scratch + (size_t)slab * m->ks_scratch_floats;
           ka.temb = nullptr; ka.resid = nullptr; ka.stat_part = nullptr; ka.bias = op.d_zero_bias;
           ka.out = scratch; ka.out_cs = ka.Co;
-          ka.ks = op.ks; ka.kt = op.kt; ka.kpart = (long long)B * V * ka.Co;
+          ka.ks = op.ks; ka.kpart = (long long)B * V * ka.Co;
           CM_HIP(cm::launch_conv(ka, op.MB, op.NB, st));
           cm::CombineArgs cb{};
-          cb.part = scratch; cb.S = op.ks * op.kt; cb.stride = ka.kpart;
+          cb.part = scratch; cb.S = op.ks; cb.stride = ka.kpart;
           cb.bias = ca.bias; cb.temb = ca.temb; cb.temb_stride = ca.temb_stride; cb.tidx = ca.tidx;
           cb.resid = ca.resid; cb.res_cs = ca.res_cs;
           cb.out = ca.out; cb.C = ka.Co; cb.V = V; cb.B = B;
