@@ -390,6 +390,25 @@ int pick_ck(int C0, int C1) {
   return 0;
 }
 
+// Measured tile choices for the layer shapes of the reference configurations (tools/tune_tiles.py on
+// one MI355X at B = 64, standalone launches): the analytic score below orders candidates well within a
+// shape class but not across accumulator blockings.  Keyed by the layer shape only -- never by the batch --
+// so the geometry, and with it every rounding, stays independent of how a batch is sharded.
+struct TunedTile { int ntaps, stride, par, Ci, Co, Zo, Yo, Xo, NB, MB, bz, by, bx; };
+const TunedTile kTunedTiles[] = {
+#include "cm_tuned_tiles.inc"
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+
+const TunedTile *find_tuned(const cm::ConvArgs &a, int NB /* 0: any */) {
+  static const bool off = getenv("CM_NO_TUNED") != nullptr;
+  if (off) return nullptr;
+  for (const TunedTile *t = kTunedTiles; t->ntaps; ++t)
+    if (t->ntaps == a.ntaps && t->stride == a.stride && t->par == a.par && t->Ci == a.C0 + a.C1 && t->Co == a.Co &&
+        t->Zo == a.Zo && t->Yo == a.Yo && t->Xo == a.Xo && (NB == 0 || t->NB == NB))
+      return t;
+  return nullptr;
+}
+
 // Tile geometry for one conv at batch B: choose the output box (bs,bz,by,bx) and
 // the per-wave accumulator blocking MB (NB is fixed by the packed weights).
 // Tile geometry is chosen for a fixed reference batch, never for the batch at hand: the
@@ -409,6 +428,17 @@ void pick_tile(Op &op, int B) {
   // the register-ring fast path (CK == 32) carries more live state than the generic one
   const bool fastp = a.CK == 32 && (a.ntaps == 27 || a.ntaps == 8);
   const int max_blk = fastp ? ((NB == 1) ? 5 : (NB == 2 ? 2 : 1)) : ((NB == 1) ? 8 : (NB == 2 ? 4 : 2));
+  if (const TunedTile *t = find_tuned(a, NB)) {
+    const int osdt = a.par ? 2 : 1;
+    a.bs = 1; a.bz = t->bz; a.by = t->by; a.bx = t->bx;
+    if (cm::conv_variant_exists(t->MB, NB) && (t->bz * t->by * t->bx + 31) / 32 == t->MB && cm::conv_lds_bytes(a, t->MB, NB) <= 64 * 1024 &&
+        (!op.small_n || !(t->MB & (t->MB - 1)))) {
+      op.MB = t->MB;
+      a.ntz = (a.Zo / osdt + a.bz - 1) / a.bz; a.nty = (a.Yo / osdt + a.by - 1) / a.by; a.ntx = (a.Xo / osdt + a.bx - 1) / a.bx;
+      op.tuned_B = B;
+      return;
+    }
+  }
   double best = -1;
   int bbs = 1, bbz = 1, bby = 1, bbx = 1, bMB = 1;
   const int ntn = (a.Co + 32 * NB - 1) / (32 * NB);
@@ -548,6 +578,12 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   // measured no better than two NB = 2 workgroups: opt-in only)
   if (s.ntaps == 27 && s.out->V() <= 64 && s.Co % 128 == 0 && getenv("CM_FAT_TILES")) op.NB = 4;
   if (s.ntaps == 27 && s.out->V() <= 64 && getenv("CM_QR_NB")) op.NB = atoi(getenv("CM_QR_NB"));
+  if (s.ntaps == 27 && s.out->V() > 64) {
+    if (const TunedTile *t = find_tuned(a, 0)) op.NB = t->NB;
+    // tuner policies (tools/tune_tiles.py): N blocking of the 64- / 128-channel 3x3x3 layers
+    if (s.Co == 64 && getenv("CM_NB64")) op.NB = atoi(getenv("CM_NB64"));
+    if (s.Co == 128 && getenv("CM_NB128")) op.NB = atoi(getenv("CM_NB128"));
+  }
   if (op.v2) {
     if (dev_alloc(m, (void **)&op.d_ctr, 64 * sizeof(int))) return 1;
     CM_HIP(hipMemset(op.d_ctr, 0, 64 * sizeof(int)));
@@ -857,6 +893,93 @@ int build_time_table(cm_model *m) {
 // ------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------
+// One convolution op of the plan for the `B` samples starting at `b0` (see run_ops).
+int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
+  if (op.skip_if_fused && !m->train_fwd) return 0;  // absorbed by the block's conv_2 (inference plan)
+  if (op.tuned_B < 0) {
+    if (op.v2) pick_tile2(op, TUNE_BATCH);
+    else pick_tile(op, TUNE_BATCH);
+    op.tuned_B = B;
+    std::vector<int> hv((size_t)cm::conv_halo_voxels(op.ca)), mt((size_t)32 * op.MB);
+    cm::conv_build_tables(op.ca, op.MB, hv.data(), mt.data());
+    if (!op.d_hvtab) {
+      if (dev_alloc(m, (void **)&op.d_hvtab, 16384 * sizeof(int))) return 1;
+      if (dev_alloc(m, (void **)&op.d_mtab, 256 * sizeof(int))) return 1;
+    }
+    if (hv.size() > 16384) return fail("halo box too large");
+    CM_HIP(hipMemcpyAsync(op.d_hvtab, hv.data(), hv.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    CM_HIP(hipMemcpyAsync(op.d_mtab, mt.data(), mt.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    CM_HIP(hipStreamSynchronize(st));
+    op.ca.hvtab = op.d_hvtab;
+    op.ca.mtab = op.d_mtab;
+  }
+  cm::ConvArgs ca = op.ca;
+  ca.B = B;
+  op.prof_B = B;
+  ca.nts = (B + ca.bs - 1) / ca.bs;
+  const size_t Vs = (size_t)ca.Zs * ca.Ys * ca.Xs, Vo = (size_t)ca.Zo * ca.Yo * ca.Xo;
+  ca.src0 += (size_t)b0 * Vs * ca.C0;
+  if (ca.src1) ca.src1 += (size_t)b0 * Vs * ca.C1;
+  if (ca.gn) ca.gn += (size_t)b0 * 2 * (ca.C0 + ca.C1);
+  ca.tidx += b0;
+  if (m->train_fwd && op.pm_off >= 0) {
+    ca.pm = m->dropmask + (size_t)b0 * m->nproj + op.pm_off;
+    ca.pm_stride = m->nproj;
+  }
+  if (m->use_train_temb && op.temb_off >= 0) {
+    ca.temb = m->train_temb + op.temb_off;
+    ca.tidx = m->train_iota + b0;
+  }
+  if (ca.resid) ca.resid += (size_t)b0 * Vo * ca.res_cs;
+  if (op.d_s2w && !m->train_fwd) {
+    if (32 * op.MB > cm::conv_halo_voxels(ca)) return fail("fused skip conv: tile rows exceed the staged box");
+    ca.s2w = op.d_s2w;
+    ca.s2src0 = op.skip0->d + (size_t)b0 * Vo * op.skip0->C; ca.s2C0 = op.skip0->C;
+    ca.s2src1 = op.skip1 ? op.skip1->d + (size_t)b0 * Vo * op.skip1->C : nullptr; ca.s2C1 = op.skip1 ? op.skip1->C : 0;
+    ca.resid = nullptr;
+    ca.bias = op.d_bias_fused;
+  }
+  ca.out += (size_t)b0 * Vo * ca.out_cs;
+  int ns = 0;
+  if (op.stat_act) {
+    ns = ca.ntz * ca.nty * ca.ntx * op.MB * (ca.par ? 8 : 1);
+    if (ns > MAX_SLOTS) return fail("statistics slots %d exceed %d", ns, MAX_SLOTS);
+    ca.stat_C = op.stat_act->C;
+    ca.stat_ns = ns;
+    ca.stat_part = op.stat_act->part + (size_t)b0 * ns * ca.stat_C * 2;
+    ca.stat_cnt = op.stat_act->cnt + (size_t)b0 * ns;
+    op.stat_act->nslots = ns;
+  }
+  if (op.ks > 1) {
+    cm::ConvArgs ka = ca;
+    const int V = op.out_act->V();
+    float *scratch = m->ks_scratch + (size_t)slab * m->ks_scratch_floats;
+    ka.temb = nullptr; ka.resid = nullptr; ka.stat_part = nullptr; ka.bias = op.d_zero_bias;
+    ka.out = scratch; ka.out_cs = ka.Co;
+    ka.ks = op.ks; ka.kpart = (long long)B * V * ka.Co;
+    CM_HIP(cm::launch_conv(ka, op.MB, op.NB, st));
+    cm::CombineArgs cb{};
+    cb.part = scratch; cb.S = op.ks; cb.stride = ka.kpart;
+    cb.bias = ca.bias; cb.temb = ca.temb; cb.temb_stride = ca.temb_stride; cb.tidx = ca.tidx;
+    cb.resid = ca.resid; cb.res_cs = ca.res_cs;
+    cb.out = ca.out; cb.C = ka.Co; cb.V = V; cb.B = B;
+    cb.nslots = (V + 31) / 32;
+    cb.stat_part = op.stat_act->part + (size_t)b0 * cb.nslots * cb.C * 2;
+    cb.stat_cnt = op.stat_act->cnt + (size_t)b0 * cb.nslots;
+    op.stat_act->nslots = cb.nslots;
+    CM_HIP(cm::launch_ksplit_combine(cb, st));
+  } else if (op.small_n) {
+    CM_HIP(cm::launch_conv_smalln(ca, op.MB, op.d_wsmall, st));
+  } else if (op.v2) {
+    const long tiles = (long)ca.ntz * ca.nty * ca.ntx * B;
+    const int gx = (int)std::min<long>(tiles, op.grid_x);
+    CM_HIP(cm::launch_conv2(ca, op.MB, op.NB, gx, op.d_ctr + 32 * slab, st));
+  } else {
+    CM_HIP(cm::launch_conv(ca, op.MB, op.NB, st));
+  }
+  return 0;
+}
+
 // Launch the op list for the `B` samples starting at sample `b0` on stream `st`.
 // Every sample-indexed pointer is offset by b0, so two disjoint sub-batches can run
 // concurrently on two streams (`slab` selects the stream's K-split scratch region).
@@ -870,91 +993,9 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
       CM_HIP(hipEventRecord(e0, st));
     }
     switch (op.kind) {
-      case OP_CONV: {
-        if (op.skip_if_fused && !m->train_fwd) break;  // absorbed by the block's conv_2 (inference plan)
-        if (op.tuned_B < 0) {
-          if (op.v2) pick_tile2(op, TUNE_BATCH);
-          else pick_tile(op, TUNE_BATCH);
-          op.tuned_B = B;
-          std::vector<int> hv((size_t)cm::conv_halo_voxels(op.ca)), mt((size_t)32 * op.MB);
-          cm::conv_build_tables(op.ca, op.MB, hv.data(), mt.data());
-          if (!op.d_hvtab) {
-            if (dev_alloc(m, (void **)&op.d_hvtab, 16384 * sizeof(int))) return 1;
-            if (dev_alloc(m, (void **)&op.d_mtab, 256 * sizeof(int))) return 1;
-          }
-          if (hv.size() > 16384) return fail("halo box too large");
-          CM_HIP(hipMemcpyAsync(op.d_hvtab, hv.data(), hv.size() * sizeof(int), hipMemcpyHostToDevice, st));
-          CM_HIP(hipMemcpyAsync(op.d_mtab, mt.data(), mt.size() * sizeof(int), hipMemcpyHostToDevice, st));
-          CM_HIP(hipStreamSynchronize(st));
-          op.ca.hvtab = op.d_hvtab;
-          op.ca.mtab = op.d_mtab;
-        }
-        cm::ConvArgs ca = op.ca;
-        ca.B = B;
-        op.prof_B = B;
-        ca.nts = (B + ca.bs - 1) / ca.bs;
-        const size_t Vs = (size_t)ca.Zs * ca.Ys * ca.Xs, Vo = (size_t)ca.Zo * ca.Yo * ca.Xo;
-        ca.src0 += (size_t)b0 * Vs * ca.C0;
-        if (ca.src1) ca.src1 += (size_t)b0 * Vs * ca.C1;
-        if (ca.gn) ca.gn += (size_t)b0 * 2 * (ca.C0 + ca.C1);
-        ca.tidx += b0;
-        if (m->train_fwd && op.pm_off >= 0) {
-          ca.pm = m->dropmask + (size_t)b0 * m->nproj + op.pm_off;
-          ca.pm_stride = m->nproj;
-        }
-        if (m->use_train_temb && op.temb_off >= 0) {
-          ca.temb = m->train_temb + op.temb_off;
-          ca.tidx = m->train_iota + b0;
-        }
-        if (ca.resid) ca.resid += (size_t)b0 * Vo * ca.res_cs;
-        if (op.d_s2w && !m->train_fwd) {
-          if (32 * op.MB > cm::conv_halo_voxels(ca)) return fail("fused skip conv: tile rows exceed the staged box");
-          ca.s2w = op.d_s2w;
-          ca.s2src0 = op.skip0->d + (size_t)b0 * Vo * op.skip0->C; ca.s2C0 = op.skip0->C;
-          ca.s2src1 = op.skip1 ? op.skip1->d + (size_t)b0 * Vo * op.skip1->C : nullptr; ca.s2C1 = op.skip1 ? op.skip1->C : 0;
-          ca.resid = nullptr;
-          ca.bias = op.d_bias_fused;
-        }
-        ca.out += (size_t)b0 * Vo * ca.out_cs;
-        int ns = 0;
-        if (op.stat_act) {
-          ns = ca.ntz * ca.nty * ca.ntx * op.MB * (ca.par ? 8 : 1);
-          if (ns > MAX_SLOTS) return fail("statistics slots %d exceed %d", ns, MAX_SLOTS);
-          ca.stat_C = op.stat_act->C;
-          ca.stat_ns = ns;
-          ca.stat_part = op.stat_act->part + (size_t)b0 * ns * ca.stat_C * 2;
-          ca.stat_cnt = op.stat_act->cnt + (size_t)b0 * ns;
-          op.stat_act->nslots = ns;
-        }
-        if (op.ks > 1) {
-          cm::ConvArgs ka = ca;
-          const int V = op.out_act->V();
-          float *scratch = m->ks_scratch + (size_t)slab * m->ks_scratch_floats;
-          ka.temb = nullptr; ka.resid = nullptr; ka.stat_part = nullptr; ka.bias = op.d_zero_bias;
-          ka.out = scratch; ka.out_cs = ka.Co;
-          ka.ks = op.ks; ka.kpart = (long long)B * V * ka.Co;
-          CM_HIP(cm::launch_conv(ka, op.MB, op.NB, st));
-          cm::CombineArgs cb{};
-          cb.part = scratch; cb.S = op.ks; cb.stride = ka.kpart;
-          cb.bias = ca.bias; cb.temb = ca.temb; cb.temb_stride = ca.temb_stride; cb.tidx = ca.tidx;
-          cb.resid = ca.resid; cb.res_cs = ca.res_cs;
-          cb.out = ca.out; cb.C = ka.Co; cb.V = V; cb.B = B;
-          cb.nslots = (V + 31) / 32;
-          cb.stat_part = op.stat_act->part + (size_t)b0 * cb.nslots * cb.C * 2;
-          cb.stat_cnt = op.stat_act->cnt + (size_t)b0 * cb.nslots;
-          op.stat_act->nslots = cb.nslots;
-          CM_HIP(cm::launch_ksplit_combine(cb, st));
-        } else if (op.small_n) {
-          CM_HIP(cm::launch_conv_smalln(ca, op.MB, op.d_wsmall, st));
-        } else if (op.v2) {
-          const long tiles = (long)ca.ntz * ca.nty * ca.ntx * B;
-          const int gx = (int)std::min<long>(tiles, op.grid_x);
-          CM_HIP(cm::launch_conv2(ca, op.MB, op.NB, gx, op.d_ctr + 32 * slab, st));
-        } else {
-          CM_HIP(cm::launch_conv(ca, op.MB, op.NB, st));
-        }
+      case OP_CONV:
+        if (run_conv(m, op, B, st, b0, slab)) return 1;
         break;
-      }
       case OP_STATS: {
         const Act *t = op.act;
         CM_HIP(cm::launch_chan_stats(t->d + (size_t)b0 * t->V() * t->C, B, t->V(), t->C, t->nslice,
@@ -1573,6 +1614,87 @@ int cm_profile_report(cm_model *m, char *buf, int64_t capacity) {
   }
   snprintf(buf, (size_t)capacity, "%s", out.c_str());
   return 0;
+}
+
+// ---- tile tuner hooks (tools/tune_tiles.py; not used by the product path) --------------------
+int cm_debug_conv_count(const cm_model *m, int32_t *count) {
+  if (!m || !m->finalized || !count) return fail("model not finalized");
+  *count = (int32_t)m->ops.size();
+  return 0;
+}
+
+// One line per op: "conv <label> ntaps stride par Ci Co Zo Yo Xo NB MB bz by bx ks flags" or "other <label>".
+int cm_debug_conv_info(const cm_model *m, int32_t index, char *buf, int64_t capacity) {
+  if (!m || !m->finalized || !buf || index < 0 || index >= (int)m->ops.size()) return fail("bad argument");
+  const Op &op = m->ops[index];
+  if (op.kind != OP_CONV) { snprintf(buf, (size_t)capacity, "other %s", op.label.c_str()); return 0; }
+  const cm::ConvArgs &a = op.ca;
+  snprintf(buf, (size_t)capacity, "conv %s %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d", op.label.c_str(), a.ntaps, a.stride, a.par,
+           a.C0 + a.C1, a.Co, a.Zo, a.Yo, a.Xo, op.NB, op.MB, a.bz, a.by, a.bx, op.ks,
+           (op.small_n ? 1 : 0) | (op.v2 ? 2 : 0) | (op.stat_act ? 4 : 0) | (op.skip_if_fused ? 8 : 0) | (a.CK == 32 ? 16 : 0));
+  return 0;
+}
+
+// Average duration (us) of `iters` back-to-back launches of conv op `index` at batch B with the tile
+// geometry (MB; bz,by,bx) -- 0 keeps the op's own.  The activations are whatever the last forward left.
+int cm_debug_time_conv(cm_model *m, int32_t index, int32_t MB, int32_t bz, int32_t by, int32_t bx, int32_t B,
+                       int32_t iters, float *us) {
+  if (check_ready(m, B)) return 1;
+  if (!us || index < 0 || index >= (int)m->ops.size() || iters < 1) return fail("bad argument");
+  Op &op = m->ops[index];
+  if (op.kind != OP_CONV || op.v2) return fail("op %d is not a tunable convolution", index);
+  if (op.tuned_B < 0) return fail("run a forward first");
+  DevGuard g(m->device);
+  hipStream_t st = m->stream;
+  const Op saved = op;
+  int rc = 0;
+  if (MB > 0) {
+    cm::ConvArgs &a = op.ca;
+    const int osd = a.par ? 2 : 1;
+    if (bz < 1 || by < 1 || bx < 1 || (bz * by * bx + 31) / 32 != MB || !cm::conv_variant_exists(MB, op.NB)) rc = fail("invalid geometry");
+    if (!rc) {
+      a.bs = 1; a.bz = bz; a.by = by; a.bx = bx;
+      op.MB = MB;
+      a.ntz = (a.Zo / osd + bz - 1) / bz; a.nty = (a.Yo / osd + by - 1) / by; a.ntx = (a.Xo / osd + bx - 1) / bx;
+      if (cm::conv_lds_bytes(a, MB, op.NB) > 64 * 1024) rc = fail("tile needs too much LDS");
+      if (!rc && op.small_n && (MB & (MB - 1))) rc = fail("small-N kernel needs a power-of-two MB");
+      if (!rc && op.stat_act && a.ntz * a.nty * a.ntx * MB * (a.par ? 8 : 1) > MAX_SLOTS) rc = fail("too many statistics slots");
+      if (!rc && cm::conv_halo_voxels(a) > 16384) rc = fail("halo box too large");
+    }
+    if (!rc) {
+      std::vector<int> hv((size_t)cm::conv_halo_voxels(a)), mt((size_t)32 * MB);
+      cm::conv_build_tables(a, MB, hv.data(), mt.data());
+      hipError_t e = hipMemcpy(op.d_hvtab, hv.data(), hv.size() * sizeof(int), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(op.d_mtab, mt.data(), mt.size() * sizeof(int), hipMemcpyHostToDevice);
+      if (e != hipSuccess) rc = fail("table upload failed");
+    }
+  }
+  if (!rc) {
+    const bool was_skip = op.skip_if_fused;
+    op.skip_if_fused = false;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 2 && !rc; ++i) rc = run_conv(m, op, B, st, 0, 0);
+    hipEventRecord(e0, st);
+    for (int i = 0; i < iters && !rc; ++i) rc = run_conv(m, op, B, st, 0, 0);
+    hipEventRecord(e1, st);
+    hipError_t e = hipStreamSynchronize(st);
+    if (!rc && e != hipSuccess) rc = fail("timed launch failed: %s", hipGetErrorString(e));
+    float ms = 0.f;
+    if (!rc) { hipEventElapsedTime(&ms, e0, e1); *us = ms * 1e3f / (float)iters; }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    op.skip_if_fused = was_skip;
+  }
+  // restore the op's own geometry and tables
+  const bool changed = MB > 0;
+  op = saved;
+  if (changed) {
+    std::vector<int> hv((size_t)cm::conv_halo_voxels(op.ca)), mt((size_t)32 * op.MB);
+    cm::conv_build_tables(op.ca, op.MB, hv.data(), mt.data());
+    CM_HIP(hipMemcpy(op.d_hvtab, hv.data(), hv.size() * sizeof(int), hipMemcpyHostToDevice));
+    CM_HIP(hipMemcpy(op.d_mtab, mt.data(), mt.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  return rc;
 }
 
 int cm_model_class_flops(const cm_model *m, int32_t B, double flops[8]) {

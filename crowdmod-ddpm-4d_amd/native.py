@@ -85,6 +85,10 @@ SIGNATURES = {
     "cm_profile_report": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "cm_model_cost": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cm_model_class_flops": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double)]),
+    "cm_debug_conv_count": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "cm_debug_conv_info": (C.c_int, [_P, C.c_int32, C.c_char_p, C.c_int64]),
+    "cm_debug_time_conv": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.POINTER(C.c_float)]),
     "cm_train_init": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     "cm_train_set_lr": (C.c_int, [_P, C.c_float]),
     "cm_train_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_float), C.c_int32, C.c_int32, _P]),

@@ -187,6 +187,13 @@ int cm_model_cost(const cm_model *m, int32_t B, double *flops, double *bytes);
 /* Algorithmic FLOPs of one forward per kernel class (same indices as cm_profile_read). */
 int cm_model_class_flops(const cm_model *m, int32_t B, double flops[8]);
 
+/* ---- tuning hooks (tools/tune_tiles.py): time one convolution of the plan with an explicit tile
+ * geometry.  Diagnostics only -- the product path never calls them. */
+int cm_debug_conv_count(const cm_model *m, int32_t *count);
+int cm_debug_conv_info(const cm_model *m, int32_t index, char *buf, int64_t capacity);
+int cm_debug_time_conv(cm_model *m, int32_t index, int32_t MB, int32_t bz, int32_t by, int32_t bx,
+                       int32_t B, int32_t iters, float *us);
+
 /* ---- training step: replaces DDPM_model._train_step + optimizer.step() -----
  * (models/diffusion/ddpm.py:111-121,142-144; optimizer built at ddpm.py:53-56:
  * torch.optim.Adam(lr, betas, weight_decay) -- L2 coupled into the gradient.)
