@@ -96,17 +96,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   (void)HVp;
 
   // ---- output row table (coordinates come packed from the host: no divisions) ----
-  for (int m = tid; m < TM; m += 256) {
-    const int pk = a.mtab[m];
-    int off = -1, bb = 0;
-    if (pk >= 0) {
-      const int x = pk & 511, y = (pk >> 9) & 511, z = (pk >> 18) & 255, s = pk >> 26;
-      const int b = b0 + s, oz = os * (z0 + z) + pz, oy = os * (y0 + y) + py, ox = os * (x0 + x) + px;
-      bb = b < a.B ? b : 0;
-      if (b < a.B && oz < a.Zo && oy < a.Yo && ox < a.Xo) off = ((b * a.Zo + oz) * a.Yo + oy) * a.Xo + ox;
-    }
-    outoff[m] = off;
-    outb[m] = bb;
+  // All table loads of the prologue (row table, LDS row bases, halo coordinates) are issued
+  // unconditionally and back to back, and decoded branch-free: a load behind a divergent branch
+  // costs its own memory round trip (~1 us under load), and there were six of them in a row.
+  static_assert(TM <= 256, "one row-table pass");
+  const int pk_row = a.mtab[tid < TM ? tid : TM - 1];
+  int pk_ab[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) pk_ab[mb] = a.mtab[mb * 32 + r];
+  {
+    const int pk = pk_row;
+    const bool v = pk >= 0;
+    const int x = pk & 511, y = (pk >> 9) & 511, z = (pk >> 18) & 255, s = v ? (pk >> 26) : 0;
+    const int b = b0 + s, oz = os * (z0 + z) + pz, oy = os * (y0 + y) + py, ox = os * (x0 + x) + px;
+    const bool in = v && b < a.B && oz < a.Zo && oy < a.Yo && ox < a.Xo;
+    const int off = in ? ((b * a.Zo + oz) * a.Yo + oy) * a.Xo + ox : -1;
+    const int bb = (v && b < a.B) ? b : 0;
+    if (tid < TM) { outoff[tid] = off; outb[tid] = bb; }
   }
   const int Zc = a.Zs << a.ups, Yc = a.Ys << a.ups, Xc = a.Xs << a.ups;
   const int cz0 = z0 * a.stride + (a.par ? pz - 1 : -pad), cy0 = y0 * a.stride + (a.par ? py - 1 : -pad),
@@ -116,12 +122,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   int abase[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    const int pk = a.mtab[mb * 32 + r];
-    int hv = 0;
-    if (pk >= 0) {
-      const int x = pk & 511, y = (pk >> 9) & 511, z = (pk >> 18) & 255, s = pk >> 26;
-      hv = ((s * HZ + z * a.stride) * HY + y * a.stride) * HX + x * a.stride;
-    }
+    const int pk = pk_ab[mb] >= 0 ? pk_ab[mb] : 0;
+    const int x = pk & 511, y = (pk >> 9) & 511, z = (pk >> 18) & 255, s = pk >> 26;
+    const int hv = ((s * HZ + z * a.stride) * HY + y * a.stride) * HX + x * a.stride;
     abase[mb] = hv * S + 4 * h;
   }
 
@@ -154,6 +157,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int TAPS = FAST ? FAST % 100 : 27;
   constexpr int PD = (TAPS == 27) ? CM_PD27 : CM_PD8;   // weight prefetch depth of the fast path (taps), TAPS % PD == 0
   f32x4 bq[PD][NB];
+  const f32x4 *wrun = wtile + ((size_t)(ch0 * TAPS + PD) * 4 + wave) * NB * 64;  // next ring refill
+  int wleft = (ch1 - ch0) * TAPS - PD;                                            // refills still to issue
   if constexpr (fast) {
 #pragma unroll
     for (int d = 0; d < PD; ++d) {
@@ -171,7 +176,38 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   const bool fstage = fast && a.bs == 1 && HV <= NVM * 32;
   int soff[NVM];
   unsigned okmask = 0;
-  if (fstage) {
+  // Row mode: a thread owns one or two whole x-rows of the halo box (row = hz * HY + hy), so the
+  // coordinate decode and the bounds of z / y happen once per row instead of once per voxel.
+  const int HR = HZ * HY, RJ = (HR + 31) >> 5;
+  const bool rowmode = fstage && a.ups == 0 && RJ * HX <= NVM && !(a.dbg & 512);
+  // slot k of a thread: (row lane j, x) in row mode, voxel v0 + 32 k otherwise
+  auto slot_j = [&](int k) { return RJ == 2 ? k / 6 : 0; };
+  auto slot_x = [&](int k) { return RJ == 2 ? k % 6 : k; };
+  auto slot_used = [&](int k) { return rowmode ? (slot_x(k) < HX && slot_j(k) < RJ) : (k * 32 < HV); };
+  auto slot_hv = [&](int k) { return rowmode ? (v0 + 32 * slot_j(k)) * HX + slot_x(k) : v0 + k * 32; };
+  auto slot_mine = [&](int k) { return rowmode ? (v0 + 32 * slot_j(k) < HR) : (v0 + k * 32 < HV); };
+  if (rowmode) {
+    int rowbase[2];
+    bool rowok[2];
+    int pkr[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) pkr[j] = a.hvtab[min(v0 + 32 * j, HR - 1) * HX];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rr = v0 + 32 * j;
+      const int pk = pkr[j];
+      const int cy = cy0 + ((pk >> 9) & 511), cz = cz0 + ((pk >> 18) & 255);
+      rowok[j] = rr < HR && b0 < a.B && cz >= 0 && cz < Zc && cy >= 0 && cy < Yc;
+      rowbase[j] = ((b0 * a.Zs + cz) * a.Ys + cy) * a.Xs;
+    }
+#pragma unroll
+    for (int k = 0; k < NVM; ++k) {
+      const int j = slot_j(k), cx = cx0 + slot_x(k);
+      const bool ok = rowok[j] && slot_used(k) && cx >= 0 && cx < Xc;
+      soff[k] = ok ? rowbase[j] + cx : 0;
+      okmask |= (ok ? 1u : 0u) << k;
+    }
+  } else if (fstage) {
     int pkk[NVM];
 #pragma unroll
     for (int k = 0; k < NVM; ++k) {
@@ -216,11 +252,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       f32x4 v[NVM];
 #pragma unroll
       for (int k = 0; k < NVM; ++k)
-        if (k * 32 < HV) v[k] = *reinterpret_cast<const f32x4 *>(srcq + (size_t)soff[k] * Cs);
+        if (slot_used(k)) v[k] = *reinterpret_cast<const f32x4 *>(srcq + (size_t)soff[k] * Cs);
 #pragma unroll
       for (int k = 0; k < NVM; ++k) {
-        const int hv = v0 + k * 32;
-        if (k * 32 < HV) {
+        const int hv = slot_hv(k);
+        if (slot_used(k)) {
           f32x4 w = v[k];
           if (a.gn && !(a.dbg & 128)) {
             w = w * sc1 + sh1;
@@ -228,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
           }
           if (a.pm) w = w * pm1;
           if (!((okmask >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (hv < HV) *reinterpret_cast<f32x4 *>(&A[hv * S + 4 * q4]) = w;
+          if (slot_mine(k)) *reinterpret_cast<f32x4 *>(&A[hv * S + 4 * q4]) = w;
         }
       }
     }
@@ -287,26 +323,30 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       // barrier exposes a weight load.
       // A fragments are read one tap ahead of their MFMAs (register double buffer), so the
       // LDS latency (bank conflicts included) hides behind 4*MB*NB MFMAs as well.
-      auto tap_off = [&](int t) {
-        int dz, dy, dx;
-        if constexpr (TAPS == 27) { dz = t / 9; const int rem = t - dz * 9; dy = rem / 3; dx = rem - dy * 3; }
-        else { dz = t >> 2; dy = (t >> 1) & 1; dx = t & 1; }
-        return ((dz * HY + dy) * HX + dx) * S + wave * 8;
-      };
+      // The matrix cores and the scalar / vector issue of a SIMD do not overlap for fp32 MFMAs
+      // (tools/ubench/mfma_valu_overlap.hip: MFMA wave + VALU wave on one SIMD take the SUM of their
+      // times), so every instruction in this loop costs its ~4 issue cycles on top of the MFMAs.
+      // Tap offsets and the weight pointer therefore advance incrementally: the PD = TD unrolled taps
+      // of one iteration are the dx steps of one (dz, dy) row of the kernel.
+      constexpr int TD = (TAPS == 27) ? 3 : 2;
+      static_assert(PD == TD, "the unrolled taps must be the dx steps of one kernel row");
+      const int step_x = S, step_y = (HX - (TD - 1)) * S, step_z = ((HY - (TD - 1)) * HX - (TD - 1)) * S;
+      int aoff = wave * 8, dyc = 0;
       f32x4 afn[MB];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) afn[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + tap_off(0)]);
+      for (int mb = 0; mb < MB; ++mb) afn[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + aoff]);
 #pragma unroll 1
       for (int i0 = 0; i0 < TAPS; i0 += PD) {
+        const int step_row = (i0 + PD >= TAPS) ? 0 : (dyc == TD - 1 ? step_z : step_y);  // (the last tap re-reads itself)
+        dyc = (dyc == TD - 1) ? 0 : dyc + 1;
 #pragma unroll
         for (int d = 0; d < PD; ++d) {
-          const int t = i0 + d;  // tap index
           f32x4 af[MB];
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) af[mb] = afn[mb];
-          const int aoffn = tap_off(t + 1 < TAPS ? t + 1 : t);  // (the last tap re-reads itself)
+          aoff += (d < PD - 1) ? step_x : step_row;
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) afn[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + aoffn]);
+          for (int mb = 0; mb < MB; ++mb) afn[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + aoff]);
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -314,13 +354,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
               for (int nb = 0; nb < NB; ++nb)
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mb][jj], bq[d][nb][jj], acc[mb][nb], 0, 0, 0);
-          // refill this ring slot with the fragments PD taps ahead (possibly next chunk)
-          int tn = t + PD, chn = ch;
-          if (tn >= TAPS) { tn -= TAPS; chn += 1; }
-          if (chn < ch1) {
-            const f32x4 *wp = (a.dbg & 64) ? wtile : wtile + ((size_t)chn * (TAPS * 4) + (wave + 4 * tn)) * NB * 64;
+          // refill this ring slot with the fragments PD taps ahead (possibly next chunk): the stream
+          // of one wave is linear in (chunk, tap), so a running pointer and a countdown suffice
+          if (wleft > 0) {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bq[d][nb] = wp[nb * 64];
+            for (int nb = 0; nb < NB; ++nb) bq[d][nb] = wrun[nb * 64];
+            wrun += 4 * NB * 64;
+            --wleft;
           }
         }
       }

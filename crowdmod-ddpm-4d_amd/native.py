@@ -14,7 +14,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrowdmod_hip.so")
+LIB_PATH = os.environ.get("CM_LIB_PATH") or os.path.join(_HERE, "libcrowdmod_hip.so")  # override: A/B of two builds
 MAX_LEVELS = 8
 
 
