@@ -1090,9 +1090,26 @@ void build_schedule(cm_schedule *s, int T, float scale, float beta_start, float 
   }
 }
 
+// torch.linspace(start, end, n)[i] in fp32: symmetric fill around the midpoint, one fused multiply-add
+// per element (the same restatement as the beta schedule; oracle/unet_numpy.py linspace_f32)
+float linspace_f32(float start, float end, int n, int i) {
+  if (n == 1) return start;
+  const double step = (double)(float)(((double)end - (double)start) / (double)(n - 1));
+  const double b = (i < n / 2) ? (double)start + step * i : (double)end - step * (n - 1 - i);
+  return (float)b;
+}
+
 std::vector<int> visit_order(const cm_schedule *s, const cm_sample_opts *o) {
   std::vector<int> v;
-  if (o->sampler == CM_SAMPLER_DDIM) {
+  if (o->sampler == CM_SAMPLER_FM_EULER) {
+    // time index per Euler step: (t * TIME_MAX_POS).clamp(0, TIME_MAX_POS - 1).long(), flow_matching.py:214
+    const int n = std::max(1, o->fm_steps), tmp = std::max(1, o->fm_time_max_pos);
+    for (int i = 0; i < n; ++i) {
+      float x = linspace_f32(0.f, 1.f, n, i) * (float)tmp;
+      x = std::min(std::max(x, 0.f), (float)(tmp - 1));
+      v.push_back((int)x);
+    }
+  } else if (o->sampler == CM_SAMPLER_DDIM) {
     const int d = std::max(1, o->ddim_divider);
     std::vector<int> taus;
     for (int t = 0; t < s->T - 1; t += d) taus.push_back(t);  // np.arange(0, T-1, divider), ddpm.py:326
@@ -1448,6 +1465,8 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
   if (check_ready(m, B)) return 1;
   if (!s || !d_past || !opts || !d_out) return fail("null argument");
   if (s->T > TIME_ROWS) return fail("timesteps %d exceed the %d-row time-embedding table (embeddings.py:7)", s->T, TIME_ROWS);
+  if (opts->sampler == CM_SAMPLER_FM_EULER && (opts->fm_steps < 1 || opts->fm_time_max_pos < 1 || opts->fm_time_max_pos > TIME_ROWS))
+    return fail("flow-matching sampler needs fm_steps >= 1 and 1 <= fm_time_max_pos <= %d", TIME_ROWS);
   DevGuard g(m->device);
   hipStream_t st = stream ? (hipStream_t)stream : m->stream;
   const cm_unet_config &c = m->cfg;
@@ -1487,7 +1506,11 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
     cm::StepArgs a{};
     a.C = c.in_channels; a.H = c.rows; a.W = c.cols; a.P = c.past_len; a.F = c.future_len;
     a.seed = opts->seed; a.step = t; a.cs = 8;
-    if (opts->sampler == CM_SAMPLER_DDIM) {
+    if (opts->sampler == CM_SAMPLER_FM_EULER) {
+      a.c_x = 1.0f; a.c_eps = (float)(1.0 / (double)opts->fm_steps); a.c_noise = 0.f;  // xt + delta * u, flow_matching.py:219
+      a.draw = 0; a.guid = 0.f;
+      a.step = (int)k;
+    } else if (opts->sampler == CM_SAMPLER_DDIM) {
       const float sab_p = s->tab[CM_TAB_SQRT_ALPHA_BAR][t], s1m_p = s->tab[CM_TAB_SQRT_ONE_MINUS_ALPHA_BAR][t];
       const float sig = opts->ddim_sigma;
       a.c_x = sab_p / sab_t;

@@ -48,6 +48,8 @@ class ReduceLROnPlateau:
 
 
 class DDPM_model:
+    _ARCHS = ("DDPM-UNet",)
+
     def __init__(self, cfg, arch, mprops_count, output_dir=None, from_fixed_past=False, *, device: int = 0,
                  seed: int = 42):
         self.cfg = cfg
@@ -72,7 +74,7 @@ class DDPM_model:
 
     def _get_denoiser(self):
         """ddpm.py:74-108."""
-        if self.arch != "DDPM-UNet":
+        if self.arch not in self._ARCHS:
             raise ValueError(f"Unknown Architecture {self.arch}")
         r = self.res
         return UNet(input_channels=self.mprops_count, output_channels=self.mprops_count,
@@ -268,14 +270,16 @@ class DDPM_model:
         """ddpm.py:156-202: epochs of _train_one_epoch, ReduceLROnPlateau on the epoch loss, NaN early
         stop, best-loss checkpoint tagged "000" and CHECKPOINTS_TO_KEEP random late epochs."""
         import logging
-        forward_sampler = DDPM(timesteps=self.res.timesteps, scale=self.res.scale, device=self.device)
+        forward_sampler = DDPM(timesteps=max(2, self.res.timesteps), scale=self.res.scale, device=self.device)
         if baseline_ckpt is not None:
             self.load_checkpoint(baseline_ckpt)
             logging.info("Baseline checkpoint loaded successfully.")
         s = self._solver()
         epochs = s["epochs"]
         best_loss, nan_run = 1e6, 0
-        keep = int(self.cfg.MODEL.get("DDPM", {}).get("CHECKPOINTS_TO_KEEP", 0) or 0)
+        keep = getattr(self, "_keep_override", None)
+        if keep is None:
+            keep = int(self.cfg.MODEL.get("DDPM", {}).get("CHECKPOINTS_TO_KEEP", 0) or 0)
         rng = np.random.default_rng(self.seed)
         to_save = set(int(v) for v in rng.integers(int(epochs * 0.75), epochs + 1, size=keep)) if keep else set()
         history = []

@@ -37,10 +37,11 @@ class cm_sample_opts(C.Structure):
         ("sampler", C.c_int32), ("guidance", C.c_int32), ("lambda_guidance", C.c_float),
         ("ddim_sigma", C.c_float), ("ddim_divider", C.c_int32), ("first_steps", C.c_int32),
         ("seed", C.c_uint64), ("sample_id_base", C.c_int64), ("use_graph", C.c_int32), ("reserved", C.c_int32),
+        ("fm_steps", C.c_int32), ("fm_time_max_pos", C.c_int32),
     ]
 
 
-SAMPLER_DDPM, SAMPLER_DDIM = 0, 1
+SAMPLER_DDPM, SAMPLER_DDIM, SAMPLER_FM_EULER = 0, 1, 2
 GUIDANCE_NONE, GUIDANCE_SPARSITY = 0, 1
 TABLES = ("beta", "alpha", "alpha_bar", "sqrt_alpha_bar", "one_by_sqrt_alpha", "sqrt_one_minus_alpha_bar")
 
@@ -89,9 +90,10 @@ SIGNATURES = {
     "cm_debug_conv_info": (C.c_int, [_P, C.c_int32, C.c_char_p, C.c_int64]),
     "cm_debug_time_conv": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.POINTER(C.c_float)]),
-    "cm_train_init": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "cm_train_init": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     "cm_train_set_lr": (C.c_int, [_P, C.c_float]),
     "cm_train_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_float), C.c_int32, C.c_int32, _P]),
+    "cm_train_step_xt": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_float), C.c_int32, C.c_int32, _P]),
     "cm_train_get_grad": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     "cm_train_sync": (C.c_int, [_P]),
     "cm_train_flat_grads": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
@@ -136,7 +138,7 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.cm_abi_version() != 1:
+    if L.cm_abi_version() != 2:
         raise NativeError("libcrowdmod_hip.so ABI version mismatch")
     _lib = L
     return L

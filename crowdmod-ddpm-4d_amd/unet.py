@@ -211,7 +211,7 @@ class UNet:
         if self._handle is None:
             raise RuntimeError("call ensure() (or run a forward) before train_init()")
         native.check(native.lib().cm_train_init(self._handle, float(lr), float(betas[0]), float(betas[1]), float(eps),
-                                                float(weight_decay)))
+                                                float(weight_decay), float(self.cfg.dropout_rate)))
         self._train_ready = True
 
     def set_lr(self, lr: float):
@@ -250,6 +250,29 @@ class UNet:
                                      deps.ptr if deps else None,
                                      dmask.ptr if dmask else None, int(seed) & 0xFFFFFFFFFFFFFFFF, C.byref(loss), B,
                                      1 if apply_update else 0, None))
+        return float(loss.value)
+
+    def train_step_xt(self, xt, past, t, target, drop_masks=None, seed: int = 0, apply_update: bool = True) -> float:
+        """The training step with the caller's noised input and regression target (flow matching):
+        loss = mse(UNet_train(xt, t, past), target); backward; Adam."""
+        L = native.lib()
+        dev = self.device
+
+        def dbuf(a, dtype):
+            if isinstance(a, native.DeviceBuffer):
+                return a
+            return native.DeviceBuffer.from_array(np.ascontiguousarray(a, dtype=dtype), dev)
+
+        B = int(t.nbytes // 8) if isinstance(t, native.DeviceBuffer) else int(np.asarray(t).size)
+        if not getattr(self, "_train_ready", False):
+            raise RuntimeError("train_init() has not been called")
+        dxt, dpst, dtg, dt = dbuf(xt, np.float32), dbuf(past, np.float32), dbuf(target, np.float32), dbuf(t, np.int64)
+        dmask = None
+        if drop_masks is not None:
+            dmask = dbuf(self._mask_rows(B, drop_masks) if isinstance(drop_masks, dict) else drop_masks, np.float32)
+        loss = C.c_float()
+        native.check(L.cm_train_step_xt(self._handle, dxt.ptr, dpst.ptr, dt.ptr, dtg.ptr, dmask.ptr if dmask else None,
+                                        int(seed) & 0xFFFFFFFFFFFFFFFF, C.byref(loss), B, 1 if apply_update else 0, None))
         return float(loss.value)
 
     def grad(self, name: str) -> np.ndarray:

@@ -62,14 +62,19 @@ def main():
     args = ap.parse_args()
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(message)s")
 
-    if args.arch != "DDPM-UNet":
-        raise SystemExit(f"{args.arch}: only DDPM-UNet is implemented on this path")
+    if args.arch not in ("DDPM-UNet", "FM-UNet"):
+        raise SystemExit(f"{args.arch}: only the UNet-backbone generators (DDPM-UNet, FM-UNet) are implemented on this path")
     cfg = cfgmod.getYamlConfig(args.config_yml_file, args.configList_yml_file)
     res = cfgmod.resolve(cfg, args.arch)
     mprops = 3  # generate_samples.py:76 of the reference
-    model = DDPM_model(cfg, args.arch, mprops, output_dir=cfg.DATA_FS.get("OUTPUT_DIR", "output"),
-                       from_fixed_past=args.from_fixed_past, device=args.device)
-    ckpt = model_fullname(cfg, args.arch, args.model_sample_to_load)
+    if args.arch == "FM-UNet":
+        from crowdmod_ddpm_4d_amd.flow_matching import FM_model as Model
+    else:
+        Model = DDPM_model
+    model = Model(cfg, args.arch, mprops, output_dir=cfg.DATA_FS.get("OUTPUT_DIR", "output"),
+                  from_fixed_past=args.from_fixed_past, device=args.device)
+    ckpt = model.checkpoint_path(args.model_sample_to_load) if args.arch == "FM-UNet" else \
+        model_fullname(cfg, args.arch, args.model_sample_to_load)
     if os.path.isfile(ckpt):
         logging.info("model full name: %s", ckpt)
         model.load_checkpoint(ckpt)

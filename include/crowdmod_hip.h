@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 1
+#define CM_ABI_VERSION 2
 #define CM_MAX_LEVELS 8
 
 typedef struct cm_model cm_model;       /* UNet denoiser: weights + workspace   */
@@ -137,7 +137,7 @@ int cm_ddpm_step(const cm_schedule *s, const float *d_eps, float *d_x, int32_t t
                  uint64_t seed, int64_t sample_id_base, int32_t B, int64_t per_sample, void *stream);
 
 /* ---- whole reverse loop --------------------------------------------------- */
-enum { CM_SAMPLER_DDPM = 0, CM_SAMPLER_DDIM = 1 };
+enum { CM_SAMPLER_DDPM = 0, CM_SAMPLER_DDIM = 1, CM_SAMPLER_FM_EULER = 2 };
 enum { CM_GUIDANCE_NONE = 0, CM_GUIDANCE_SPARSITY = 1 };
 
 typedef struct cm_sample_opts {
@@ -151,6 +151,11 @@ typedef struct cm_sample_opts {
   int64_t sample_id_base; /* global index of sample 0 (batch sharding)           */
   int32_t use_graph;      /* replay the per-step launch sequence as a hipGraph   */
   int32_t reserved;
+  /* CM_SAMPLER_FM_EULER -- FM_model.sampling_with_euler (models/flow_matching/flow_matching.py:203-224):
+   * x <- x + (1/N) u(x, idx_i, past) for t_i = linspace(0,1,N)[i], idx_i = clamp(t_i * TIME_MAX_POS, 0,
+   * TIME_MAX_POS-1) truncated; the schedule handle is not consulted. */
+  int32_t fm_steps;        /* cfg.MODEL.FM.INTEGRATOR_STEPS.EULER                 */
+  int32_t fm_time_max_pos; /* cfg.MODEL.FM.TIME_MAX_POS (<= 1000 table rows)      */
 } cm_sample_opts;
 
 /* DDPM_model._generate_ddpm / _generate_ddim (ddpm.py:206-282): all T (or
@@ -199,7 +204,8 @@ int cm_debug_time_conv(cm_model *m, int32_t index, int32_t MB, int32_t bz, int32
  * torch.optim.Adam(lr, betas, weight_decay) -- L2 coupled into the gradient.)
  * cm_train_init allocates master weights / gradients / Adam moments on the device
  * (state_dict order) and the backward workspace; call once after cm_model_finalize. */
-int cm_train_init(cm_model *m, float lr, float beta1, float beta2, float eps, float weight_decay);
+int cm_train_init(cm_model *m, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float dropout_rate /* cfg DROPOUT_RATE: nn.Dropout3d(p), layers.py:42 */);
 int cm_train_set_lr(cm_model *m, float lr);
 /* One step on device buffers:
  *   x_t = q_sample(d_future, d_t, d_eps)          (forward.py:29-35 with the caller's noise)
@@ -221,6 +227,12 @@ int cm_train_apply(cm_model *m, void *stream);
 int cm_train_get_opt_state(cm_model *m, const char *name, int32_t which, float *h_out, int64_t numel);
 int cm_train_set_opt_state(cm_model *m, const char *name, int32_t which, const float *h_in, int64_t numel);
 int cm_train_opt_step(cm_model *m, int32_t *step, int32_t set);
+/* The same step with the caller's noised input and regression target (flow matching,
+ * flow_matching.py:128-146: x_t and u_target from w_linear / w_conic, d_t = (t * TIME_MAX_POS).long()):
+ * eps_hat = UNet(d_xt, d_t, d_past) in train mode; *h_loss = mse(eps_hat, d_target); backward; update. */
+int cm_train_step_xt(cm_model *m, const float *d_xt, const float *d_past, const int64_t *d_t,
+                     const float *d_target, const float *d_dropmask, uint64_t seed, float *h_loss,
+                     int32_t B, int32_t apply_update, void *stream);
 /* Gradient of one state_dict tensor after the last cm_train_step (reference layout). */
 int cm_train_get_grad(cm_model *m, const char *name, float *h_out, int64_t numel);
 /* Copy the trained master weights back into the handle's state_dict (cm_model_get_param then

@@ -12,6 +12,7 @@ What is captured:
   fwd.npz           full-width UNet outputs on the ATC / CR-120 / 2x grids
   loop.npz          _generate_ddpm / _generate_ddim results with injected noise
   train.npz         loss + per-tensor gradient norms of one training step
+  fm.npz            flow matching: Euler sampling + one training step per probability path
 
 Weights and inputs are NOT stored: both sides regenerate them bit-identically
 from the integer PRNG (crowdmod-ddpm-4d_amd/prng.py, spec.init_params).
@@ -340,9 +341,77 @@ def gen_train(out):
     print("train loss", float(loss), "second step", float(loss2))
 
 
+def gen_fm(out):
+    """Flow matching on the UNet backbone (models/flow_matching/flow_matching.py): the reference's own
+    FM_model.sampling_with_euler with x_0 injected (torch.randn patched) on the narrow model, and one
+    training step of _train_one_epoch_fm's body for the Linear and the Conic path with x_0, t and the
+    Dropout3d masks injected (loss + gradient norms)."""
+    AttrDict = _placeholders()
+    import torch.nn as nn
+    from models.backbones import layers as RL
+    from models.flow_matching import flow_matching as RF
+    C, B = 3, 2
+    g = NARROW
+    ucfg = narrow_cfg(C)
+    params = spec.init_params(ucfg, SEED_W)
+    cfg = AttrDict({
+        "MACROPROPS": {"ROWS": g["H"], "COLS": g["W"]},
+        "DATASET": {"PAST_LEN": g["P"], "FUTURE_LEN": g["F"], "BATCH_SIZE": B},
+        "MODEL": {"NSAMPLES4PLOTS": B, "FM": {
+            "TIME_MAX_POS": 1000, "CHECKPOINTS_TO_KEEP": 1, "W_TYPE": "Linear", "INTEGRATOR": "Euler",
+            "INTEGRATOR_STEPS": {"EULER": 8, "HEUN": 4},
+            "UNET": {"CONDITION": "Past", "NUM_RES_BLOCKS": 1, "BASE_CH": 8, "BASE_CH_MULT": [1, 2, 4],
+                     "APPLY_ATTENTION": [False, False, True, False], "DROPOUT_RATE": 0.1, "TIME_EMB_MULT": 4,
+                     "TRAIN": {"EPOCHS": 1, "SOLVER": {"LR": 1e-4, "BETAS": [0.5, 0.999], "WEIGHT_DECAY": 0.001,
+                               "SCHEDULER": {"FACTOR": 0.5, "PATIENCE": 10, "MIN_LR": 1e-6}}}}}}})
+    model = RF.FM_model(cfg, "FM-UNet", C)
+    model.u_predictor.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    d = {}
+    past, fut = synth_inputs(B, C, g["H"], g["W"], g["P"], g["F"], "fm")
+    x0 = prng.normal(SEED_X, "fm/x0", fut.size).reshape(fut.shape)
+    o = torch.randn
+    torch.randn = lambda *a, **kw: torch.from_numpy(x0.copy())
+    try:
+        d["euler8"] = model.sampling_with_euler(torch.from_numpy(past), B).numpy()
+    finally:
+        torch.randn = o
+    # training step body (flow_matching.py:128-146) with injected x0 / t / masks
+    t = np.array([0.137, 0.862], dtype=np.float32)
+    d["t"] = t
+
+    class FixedDrop(nn.Module):
+        def __init__(self, mask):
+            super().__init__()
+            self.mask = mask
+
+        def forward(self, x):
+            return x * self.mask[:, :, None, None, None]
+
+    net = model.u_predictor.train()
+    for name, mod in net.named_modules():
+        if isinstance(mod, RL.ResnetBlock):
+            u = prng.uniform_pm1(SEED_X, f"drop/{name}", B * mod.out_channels).reshape(B, mod.out_channels)
+            keep = ((u * 0.5 + 0.5) >= 0.1).astype(np.float32) / np.float32(0.9)
+            mod.dropout = FixedDrop(torch.from_numpy(keep))
+    for wtype in ("Linear", "Conic"):
+        net.zero_grad(set_to_none=True)
+        tt = torch.from_numpy(t).view(-1, 1, 1, 1, 1)
+        xt, u_target = model.w_type_fns[wtype](torch.from_numpy(x0), torch.from_numpy(fut), tt)
+        u_pred = net(xt, (tt * cfg.MODEL.FM.TIME_MAX_POS).long().view(-1), torch.from_numpy(past))
+        loss = ((u_target - u_pred) ** 2).mean()
+        loss.backward()
+        d[f"{wtype}/loss"] = np.float32(loss.item())
+        d[f"{wtype}/pred"] = u_pred.detach().numpy()
+        for name, prm in net.named_parameters():
+            if prm.grad is not None and (name.endswith("conv_2.weight") or name.startswith("final") or name.startswith("first")):
+                d[f"{wtype}/gnorm/{name}"] = np.float32(prm.grad.norm().item())
+    np.savez_compressed(os.path.join(out, "fm.npz"), **d)
+    print("fm euler |x|max", float(np.abs(d["euler8"]).max()), "losses", float(d["Linear/loss"]), float(d["Conic/loss"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="schedule,ops,fwd,loop,train")
+    ap.add_argument("--only", default="schedule,ops,fwd,loop,train,fm")
     ap.add_argument("--out", default=HERE)
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -355,6 +424,8 @@ def main():
         gen_fwd(a.out)
     if "train" in todo:
         gen_train(a.out)
+    if "fm" in todo:
+        gen_fm(a.out)
     if "loop" in todo:
         gen_loop(a.out)
 

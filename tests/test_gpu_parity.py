@@ -379,3 +379,75 @@ def test_train_loop_checkpoint_and_resume(tmp_path):
         out.append((l, mm.denoiser.state_dict()["encoder_blocks.0.conv_1.weight"].copy()))
     assert abs(out[0][0] - out[1][0]) <= 1e-6 * max(1.0, abs(out[0][0]))
     assert np.abs(out[0][1] - out[1][1]).max() <= 1e-7
+
+
+def _fm_setup():
+    from crowdmod_ddpm_4d_amd.config import AttrDict
+    from crowdmod_ddpm_4d_amd.flow_matching import FM_model
+    C_, B = 3, 2
+    cfg = AttrDict({
+        "MACROPROPS": {"ROWS": NARROW["H"], "COLS": NARROW["W"]},
+        "DATASET": {"NAME": "synthetic", "PAST_LEN": NARROW["P"], "FUTURE_LEN": NARROW["F"], "BATCH_SIZE": B},
+        "DATA_FS": {"SAVE_DIR": "/tmp/"},
+        "MODEL": {"NAME": "{}_SYN_TE{}_PL{}_FL{}_CE{}_{}.pth", "NSAMPLES4PLOTS": B, "FM": {
+            "TIME_MAX_POS": 1000, "CHECKPOINTS_TO_KEEP": 1, "W_TYPE": "Linear", "INTEGRATOR": "Euler",
+            "INTEGRATOR_STEPS": {"EULER": 8, "HEUN": 4},
+            "UNET": {"CONDITION": "Past", "NUM_RES_BLOCKS": 1, "BASE_CH": 8, "BASE_CH_MULT": [1, 2, 4],
+                     "APPLY_ATTENTION": [False, False, True, False], "DROPOUT_RATE": 0.1, "TIME_EMB_MULT": 4,
+                     "TRAIN": {"EPOCHS": 1, "SOLVER": {"LR": 1e-4, "BETAS": [0.5, 0.999], "WEIGHT_DECAY": 0.001,
+                               "SCHEDULER": {"FACTOR": 0.5, "PATIENCE": 10, "MIN_LR": 1e-6}}}}}}})
+    m = FM_model(cfg, "FM-UNet", C_)
+    m.denoiser.load_state_dict(spec.init_params(narrow_cfg(C_), SEED_W))
+    past, fut = synth_inputs(B, C_, NARROW["H"], NARROW["W"], NARROW["P"], NARROW["F"], "fm")
+    x0 = prng.normal(7, "fm/x0", fut.size).reshape(fut.shape)
+    return m, past, fut, x0
+
+
+@pytest.mark.gpu
+def test_flow_matching_euler_sampling_vs_reference():
+    """FM_model.sampling_with_euler (flow_matching.py:203-224), 8 steps, x_0 injected: the whole integration
+    runs as one device loop; against the reference's own routine on the narrow model."""
+    g = load("fm.npz")
+    m, past, fut, x0 = _fm_setup()
+    x = m.sampling_with_euler(past, 2, x0=x0)
+    assert np.abs(x - g["euler8"]).max() <= TOL
+    assert m.integrators["Heun"] == m.integrators["Euler"]   # flow_matching.py:44-47 maps both to Euler
+    # device-drawn x_0: deterministic per seed, different from the injected run
+    m2, *_ = _fm_setup()
+    a = m2.sampling_with_euler(past, 2)
+    m3, *_ = _fm_setup()
+    b = m3.sampling_with_euler(past, 2)
+    assert np.array_equal(a, b) and not np.array_equal(a, x)
+
+
+@pytest.mark.gpu
+def test_flow_matching_train_step_vs_reference():
+    """Body of _train_one_epoch_fm (flow_matching.py:128-146) for both probability paths with x_0, t and the
+    Dropout3d masks injected: loss and gradient norms of the conv_2 / first / final tensors."""
+    g = load("fm.npz")
+    for wtype in ("Linear", "Conic"):
+        m, past, fut, x0 = _fm_setup()
+        m.w_type = wtype
+        masks = {}
+        for blk in spec.make_plan(narrow_cfg(3)).res_blocks():
+            u = prng.uniform_pm1(7, f"drop/{blk.prefix}", 2 * blk.cout).reshape(2, blk.cout)
+            masks[blk.prefix] = ((u * 0.5 + 0.5) >= 0.1).astype(np.float32) / np.float32(0.9)
+        m._ensure_training(past, fut)
+        t = g["t"]
+        xt, u_target = m.w_type_fns[wtype](x0, fut, t.reshape(-1, 1, 1, 1, 1))
+        t_idx = (t * np.float32(1000)).astype(np.int64)
+        loss = m.denoiser.train_step_xt(xt.astype(np.float32), past, t_idx, u_target.astype(np.float32), drop_masks=masks,
+                                        apply_update=False)
+        ref = float(g[f"{wtype}/loss"])
+        assert abs(loss - ref) <= 2e-5 * max(1.0, ref), (wtype, loss, ref)
+        for key in g.files:
+            if key.startswith(f"{wtype}/gnorm/"):
+                name = key.split("/", 2)[2]
+                got = float(np.sqrt((m.denoiser.grad(name).astype(np.float64) ** 2).sum()))
+                assert abs(got - float(g[key])) <= 2e-3 * float(g[key]) + 2e-7, (wtype, name, got, float(g[key]))
+    # one epoch through the mirror's own loop (device dropout, host-drawn x_0 / t): finite loss, weights move
+    m, past, fut, _ = _fm_setup()
+    before = m.denoiser.state_dict()["final.2.weight"].copy()
+    l = m._train_one_epoch_fm([(past, fut)], 1)
+    m.denoiser.sync_trained()
+    assert np.isfinite(l) and not np.array_equal(before, m.denoiser.state_dict()["final.2.weight"])

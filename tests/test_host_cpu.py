@@ -27,7 +27,7 @@ def test_library_exports_every_symbol_of_the_header():
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, missing
     assert names == set(native.SIGNATURES), names ^ set(native.SIGNATURES)
-    assert lib.cm_abi_version() == 1
+    assert lib.cm_abi_version() == 2
 
 
 def test_error_reporting_without_gpu_is_loud():

@@ -59,19 +59,20 @@ def main():
     ap.add_argument('--device', type=int, default=None)
     args = ap.parse_args()
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(message)s")
-    if args.arch != "DDPM-UNet":
-        raise SystemExit(f"{args.arch}: only DDPM-UNet is implemented on this path")
+    if args.arch not in ("DDPM-UNet", "FM-UNet"):
+        raise SystemExit(f"{args.arch}: only the UNet-backbone generators (DDPM-UNet, FM-UNet) are implemented on this path")
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     device = args.device if args.device is not None else int(os.environ.get("LOCAL_RANK", 0))
 
     from crowdmod_ddpm_4d_amd.ddpm_model import DDPM_model
+    from crowdmod_ddpm_4d_amd.flow_matching import FM_model
     from generate_samples import windows
     cfg = cfgmod.getYamlConfig(args.config_yml_file, args.configList_yml_file)
     res = cfgmod.resolve(cfg, args.arch)
     if args.epochs is not None and res.train is not None:
         res.train["EPOCHS"] = int(args.epochs)
     mprops = 3  # train.py:61 of the reference
-    model = DDPM_model(cfg, args.arch, mprops, device=device)
+    model = (FM_model if args.arch == "FM-UNet" else DDPM_model)(cfg, args.arch, mprops, device=device)
     if args.epochs is not None:
         model.res = res
     nparams = sum(int(np.prod(v.shape)) for k, v in model.denoiser.state_dict().items()
