@@ -148,6 +148,9 @@ hipError_t launch_dropout_mask(float *mask, int B, int C, float p, unsigned long
                                int step, hipStream_t st);
 hipError_t launch_randn(float *x, int B, long long per, unsigned long long seed, long long sample_id_base, int step,
                         hipStream_t st);
+// per-(sample, channel, frame) reductions of the sampling metrics (see cm_misc.hip)
+hipError_t launch_frame_metrics(const float *pred, const float *gt, int N, int C, int H, int W, int F, double *out,
+                                float *minmax, hipStream_t st);
 // generic strided copy channels-last -> reference layout (debug hook)
 hipError_t launch_cl_to_ref(const float *x_cl, int cs, float *out, int B, int C, int Z, int Y, int X, hipStream_t st);
 

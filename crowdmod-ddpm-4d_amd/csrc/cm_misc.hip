@@ -260,6 +260,70 @@ hipError_t launch_ksplit_combine(const CombineArgs &a, hipStream_t st) {
 }
 
 // --------------------------------------------------------------------------------
+// Per-(sample, channel, frame) reductions behind the reference's sampling metrics
+// (utils/metrics/metricsGenerator.py:70-92,120-186,293-339): squared error, squared error and
+// count under the density mask gt[0] > 1e-5, total variation of prediction and ground truth,
+// plane sums, and the ground-truth min / max per (sample, channel) for the data ranges.
+// pred / gt: [N, C, H, W, F] (reference layout).  One workgroup per (frame, channel, sample);
+// sums in double like np.mean(..., dtype=float64), fixed order.
+// out [N][C][F][8] doubles: sse, masked sse, masked count, tv_pred, tv_gt, sum_pred, sum_gt, unused
+// minmax [N][C][F][2] floats: min / max of the gt plane (reduced over frames on the host).
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frame_metrics_kernel(const float *__restrict__ pred, const float *__restrict__ gt,
+                                                            int C, int H, int W, int F, double *__restrict__ out,
+                                                            float *__restrict__ minmax) {
+  __shared__ double sh[7][256];
+  __shared__ float shm[2][256];
+  const int j = blockIdx.x, c = blockIdx.y, n = blockIdx.z, tid = threadIdx.x;
+  const size_t plane = ((size_t)n * C + c) * H * W * F;        // element (h, w, j) at plane + (h*W + w)*F + j
+  const size_t plane0 = ((size_t)n * C + 0) * H * W * F;       // density channel: the mask
+  double a[7] = {0, 0, 0, 0, 0, 0, 0};
+  float mn = 3.0e38f, mx = -3.0e38f;
+  for (int i = tid; i < H * W; i += 256) {
+    const int h = i / W, w = i - h * W;
+    const float g = gt[plane + (size_t)i * F + j], p = pred[plane + (size_t)i * F + j];
+    const float d = g - p;
+    a[0] += (double)d * (double)d;
+    if (gt[plane0 + (size_t)i * F + j] > 0.00001f) { a[1] += (double)d * (double)d; a[2] += 1.0; }
+    if (h + 1 < H) {
+      a[3] += (double)fabsf(pred[plane + (size_t)(i + W) * F + j] - p);
+      a[4] += (double)fabsf(gt[plane + (size_t)(i + W) * F + j] - g);
+    }
+    if (w + 1 < W) {
+      a[3] += (double)fabsf(pred[plane + (size_t)(i + 1) * F + j] - p);
+      a[4] += (double)fabsf(gt[plane + (size_t)(i + 1) * F + j] - g);
+    }
+    a[5] += (double)p;
+    a[6] += (double)g;
+    mn = fminf(mn, g);
+    mx = fmaxf(mx, g);
+  }
+  for (int k = 0; k < 7; ++k) sh[k][tid] = a[k];
+  shm[0][tid] = mn; shm[1][tid] = mx;
+  __syncthreads();
+  if (tid < 8) {
+    double *o = out + ((((size_t)n * C + c) * F + j) * 8);
+    if (tid < 7) {
+      double s = 0;
+      for (int l = 0; l < 256; ++l) s += sh[tid][l];
+      o[tid] = s;
+    } else {
+      float lo = 3.0e38f, hi = -3.0e38f;
+      for (int l = 0; l < 256; ++l) { lo = fminf(lo, shm[0][l]); hi = fmaxf(hi, shm[1][l]); }
+      o[7] = 0.0;
+      minmax[(((size_t)n * C + c) * F + j) * 2 + 0] = lo;
+      minmax[(((size_t)n * C + c) * F + j) * 2 + 1] = hi;
+    }
+  }
+}
+
+hipError_t launch_frame_metrics(const float *pred, const float *gt, int N, int C, int H, int W, int F, double *out,
+                                float *minmax, hipStream_t st) {
+  hipLaunchKernelGGL(frame_metrics_kernel, dim3(F, C, N), dim3(256), 0, st, pred, gt, C, H, W, F, out, minmax);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
 // ABI edge: reference layout [B,C,H,W,L] <-> channels-last [B][L][H][W][8].
 // unet.py:138 (cat past||future on L) and unet.py:166 (keep frames >= P) are folded in.
 // --------------------------------------------------------------------------------

@@ -1639,6 +1639,27 @@ int cm_profile_report(cm_model *m, char *buf, int64_t capacity) {
   return 0;
 }
 
+// ---- sampling metrics: the reductions of utils/metrics/metricsGenerator.py on the device ------
+int cm_frame_metrics(int32_t device, const float *d_pred, const float *d_gt, int32_t N, int32_t Cc, int32_t H, int32_t W,
+                     int32_t F, double *h_out, float *h_minmax) {
+  if (!d_pred || !d_gt || !h_out || !h_minmax) return fail("null argument");
+  if (N < 1 || Cc < 1 || H < 1 || W < 1 || F < 1) return fail("bad shape");
+  DevGuard g(device);
+  const size_t cells = (size_t)N * Cc * F;
+  double *d_out = nullptr;
+  float *d_mm = nullptr;
+  CM_HIP(hipMalloc((void **)&d_out, cells * 8 * sizeof(double)));
+  hipError_t e = hipMalloc((void **)&d_mm, cells * 2 * sizeof(float));
+  if (e == hipSuccess) e = cm::launch_frame_metrics(d_pred, d_gt, N, Cc, H, W, F, d_out, d_mm, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(h_out, d_out, cells * 8 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(h_minmax, d_mm, cells * 2 * sizeof(float), hipMemcpyDeviceToHost);
+  hipFree(d_out);
+  if (d_mm) hipFree(d_mm);
+  if (e != hipSuccess) return fail("frame metrics failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
 // ---- tile tuner hooks (tools/tune_tiles.py; not used by the product path) --------------------
 int cm_debug_conv_count(const cm_model *m, int32_t *count) {
   if (!m || !m->finalized || !count) return fail("model not finalized");

@@ -192,6 +192,14 @@ int cm_model_cost(const cm_model *m, int32_t B, double *flops, double *bytes);
 /* Algorithmic FLOPs of one forward per kernel class (same indices as cm_profile_read). */
 int cm_model_class_flops(const cm_model *m, int32_t B, double flops[8]);
 
+/* ---- sampling metrics: the per-frame reductions of utils/metrics/metricsGenerator.py:70-92,
+ * 120-186,293-339 (PSNR, masked PSNR, relative density error, total variation) on the device.
+ *   d_pred, d_gt [N,C,H,W,F] f32 (device);  h_out [N][C][F][8] f64: sse, masked sse, masked count
+ *   (mask = gt[:,0] > 1e-5), tv_pred, tv_gt, sum_pred, sum_gt, 0;  h_minmax [N][C][F][2] f32: min / max
+ *   of the gt plane.  The log10 / max-over-repeats tail on [N,C,F] numbers stays on the host. */
+int cm_frame_metrics(int32_t device, const float *d_pred, const float *d_gt, int32_t N, int32_t C, int32_t H,
+                     int32_t W, int32_t F, double *h_out, float *h_minmax);
+
 /* ---- tuning hooks (tools/tune_tiles.py): time one convolution of the plan with an explicit tile
  * geometry.  Diagnostics only -- the product path never calls them. */
 int cm_debug_conv_count(const cm_model *m, int32_t *count);

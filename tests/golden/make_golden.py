@@ -12,6 +12,7 @@ What is captured:
   fwd.npz           full-width UNet outputs on the ATC / CR-120 / 2x grids
   loop.npz          _generate_ddpm / _generate_ddim results with injected noise
   train.npz         loss + per-tensor gradient norms of one training step
+  metrics.npz       PSNR / masked PSNR / relative density / TV tables of the reference's MetricsGenerator
   fm.npz            flow matching: Euler sampling + one training step per probability path
 
 Weights and inputs are NOT stored: both sides regenerate them bit-identically
@@ -409,9 +410,41 @@ def gen_fm(out):
     print("fm euler |x|max", float(np.abs(d["euler8"]).max()), "losses", float(d["Linear/loss"]), float(d["Conic/loss"]))
 
 
+def gen_metrics(out):
+    """The reduction-type metrics of the reference's MetricsGenerator (utils/metrics/metricsGenerator.py):
+    PSNR / masked PSNR (+ MAX, + over time), relative density error (+ MIN), TV over time, on 8 synthetic
+    (prediction, ground truth) sequences = 2 pasts x 4 repeats."""
+    AttrDict = _placeholders()
+    from utils.metrics.metricsGenerator import MetricsGenerator
+    N, C, H, W, F, chunk = 8, 3, 12, 36, 3, 4
+    gt = prng.normal(SEED_X, "metrics/gt", N * C * H * W * F).reshape(N, C, H, W, F)
+    gt[:, 0] = np.maximum(gt[:, 0], 0.0)          # density: non-negative with empty cells (the mask matters)
+    gt[0, 0, :, :, 2] = 0.0                        # one frame with an empty mask (replicated over its repeats)
+    pred = (gt + 0.3 * prng.normal(SEED_X, "metrics/noise", gt.size).reshape(gt.shape)).astype(np.float32)
+    for i in range(0, N, chunk):                   # repeats of one past share the ground truth
+        gt[i:i + chunk] = gt[i]
+    gt = gt.astype(np.float32)
+    mg = MetricsGenerator([torch.from_numpy(p) for p in pred], [torch.from_numpy(g) for g in gt],
+                          AttrDict({"MPROPS_COUNT": 3}), None)
+    eps = 1e-8
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mg.compute_psnr_metric(chunk, eps, masked_flag=False)
+        mg.compute_psnr_metric(chunk, eps, masked_flag=True)
+    mg.compute_re_density_metric(chunk, eps)
+    mg.compute_tv_metric()
+    d = {"ranges": np.array([mg.rho_range, mg.vx_range, mg.vy_range]), "chunk": np.int64(chunk), "eps": np.float64(eps)}
+    for k in ("PSNR", "MAX_PSNR", "PSNR_OVER_TIME", "MAX_PSNR_OVER_TIME", "MASK_PSNR", "MAX_MASK_PSNR", "MASK_PSNR_OVER_TIME",
+              "MAX_MASK_PSNR_OVER_TIME", "RE_DENSITY", "MIN_RE_DENSITY", "TV_OVER_TIME"):
+        d[k] = np.asarray(mg.data_dict[k], dtype=np.float64)
+    np.savez_compressed(os.path.join(out, "metrics.npz"), **d)
+    print("metrics psnr", d["PSNR"][0], "masked nan count", int(np.isnan(d["MASK_PSNR_OVER_TIME"]).sum()))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="schedule,ops,fwd,loop,train,fm")
+    ap.add_argument("--only", default="schedule,ops,fwd,loop,train,fm,metrics")
     ap.add_argument("--out", default=HERE)
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -426,6 +459,8 @@ def main():
         gen_train(a.out)
     if "fm" in todo:
         gen_fm(a.out)
+    if "metrics" in todo:
+        gen_metrics(a.out)
     if "loop" in todo:
         gen_loop(a.out)
 

@@ -451,3 +451,32 @@ def test_flow_matching_train_step_vs_reference():
     l = m._train_one_epoch_fm([(past, fut)], 1)
     m.denoiser.sync_trained()
     assert np.isfinite(l) and not np.array_equal(before, m.denoiser.state_dict()["final.2.weight"])
+
+
+@pytest.mark.gpu
+def test_frame_metrics_vs_reference_tables():
+    """Device reductions behind PSNR / masked PSNR / relative density / TV (metricsGenerator.py:70-92,120-186,
+    293-339) against the tables the reference's MetricsGenerator produced for the same sequences, including
+    a frame whose density mask is empty (NaN like the reference's mean over an empty selection)."""
+    from crowdmod_ddpm_4d_amd.metrics import MetricsGenerator
+    g = load("metrics.npz")
+    N, C_, H, W, F, chunk = 8, 3, 12, 36, 3, int(g["chunk"])
+    gt = prng.normal(7, "metrics/gt", N * C_ * H * W * F).reshape(N, C_, H, W, F)
+    gt[:, 0] = np.maximum(gt[:, 0], 0.0)
+    gt[0, 0, :, :, 2] = 0.0
+    pred = (gt + 0.3 * prng.normal(7, "metrics/noise", gt.size).reshape(gt.shape)).astype(np.float32)
+    for i in range(0, N, chunk):
+        gt[i:i + chunk] = gt[i]
+    mg = MetricsGenerator(pred, gt.astype(np.float32), 3)
+    np.testing.assert_allclose(mg.ranges, g["ranges"], rtol=1e-6)
+    eps = float(g["eps"])
+    mg.compute_psnr_metric(chunk, eps, masked_flag=False)
+    mg.compute_psnr_metric(chunk, eps, masked_flag=True)
+    mg.compute_re_density_metric(chunk, eps)
+    mg.compute_tv_metric()
+    for k in ("PSNR", "MAX_PSNR", "PSNR_OVER_TIME", "MAX_PSNR_OVER_TIME", "MASK_PSNR", "MAX_MASK_PSNR", "MASK_PSNR_OVER_TIME",
+              "MAX_MASK_PSNR_OVER_TIME", "RE_DENSITY", "MIN_RE_DENSITY"):
+        np.testing.assert_allclose(mg.data_dict[k], g[k], rtol=2e-6, atol=1e-6, equal_nan=True, err_msg=k)
+    # total variation: the reference sums |diff| in float32 (pairwise), the device in double
+    np.testing.assert_allclose(mg.data_dict["TV_OVER_TIME"], g["TV_OVER_TIME"], rtol=0, atol=2e-3, err_msg="TV")
+    assert np.isnan(g["MASK_PSNR_OVER_TIME"]).any()

@@ -172,3 +172,32 @@ def test_loop_ddpm1000_checkpoints():
         err = np.abs(kept[t] - ref).max() / max(1.0, np.abs(ref).max())
         assert err <= 1e-5, (t, err)
     assert np.array_equal(kept[0], x)
+
+
+def test_metrics_oracle_vs_reference_tables():
+    """oracle/metrics_numpy.py against the tables of the reference's MetricsGenerator (tests/golden/metrics.npz)."""
+    import warnings
+    from crowdmod_ddpm_4d_amd import prng
+    from oracle import metrics_numpy as om
+    g = load("metrics.npz")
+    N, C_, H, W, F, chunk = 8, 3, 12, 36, 3, int(g["chunk"])
+    gt = prng.normal(7, "metrics/gt", N * C_ * H * W * F).reshape(N, C_, H, W, F)
+    gt[:, 0] = np.maximum(gt[:, 0], 0.0)
+    gt[0, 0, :, :, 2] = 0.0
+    pred = (gt + 0.3 * prng.normal(7, "metrics/noise", gt.size).reshape(gt.shape)).astype(np.float32)
+    for i in range(0, N, chunk):
+        gt[i:i + chunk] = gt[i]
+    gt = gt.astype(np.float32)
+    eps = float(g["eps"])
+    np.testing.assert_allclose(om.ranges(gt), g["ranges"], rtol=1e-7)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a, mx, ot, mxt = om.psnr_tables(pred, gt, chunk, eps, False)
+        am, mxm, otm, mxtm = om.psnr_tables(pred, gt, chunk, eps, True)
+    for got, key in ((a, "PSNR"), (mx, "MAX_PSNR"), (ot, "PSNR_OVER_TIME"), (mxt, "MAX_PSNR_OVER_TIME"), (am, "MASK_PSNR"),
+                     (mxm, "MAX_MASK_PSNR"), (otm, "MASK_PSNR_OVER_TIME"), (mxtm, "MAX_MASK_PSNR_OVER_TIME")):
+        np.testing.assert_allclose(got, g[key], rtol=1e-10, equal_nan=True, err_msg=key)
+    re, mre = om.re_density(pred, gt, chunk, eps)
+    np.testing.assert_allclose(re, g["RE_DENSITY"], rtol=1e-6)
+    np.testing.assert_allclose(mre, g["MIN_RE_DENSITY"], rtol=1e-6)
+    np.testing.assert_allclose(om.tv_over_time(pred, gt), g["TV_OVER_TIME"], rtol=1e-6, atol=1e-4)
