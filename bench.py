@@ -108,11 +108,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # rehearsal switches (one-GPU box): CM_BENCH_BACKEND=gloo CM_BENCH_SHARE_GPU=1 run N ranks on cuda:0 to
+    # exercise the multi-rank control flow; the driver's N-GPU runs use neither
+    backend = os.environ.get("CM_BENCH_BACKEND", "nccl")
+    if os.environ.get("CM_BENCH_SHARE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     cfg, res = load_cfg(a.channels)
     Cn, B = a.channels, a.batch
@@ -140,12 +148,13 @@ def main():
     t0 = time.perf_counter()
     x = run(a.steps)
     if dist is not None:
-        gathered = [torch.empty_like(x) for _ in range(world)]
-        dist.all_gather(gathered, x)  # the trivial gather of the sharded result (RCCL over xGMI)
+        xg = x if backend == "nccl" else x.cpu()
+        gathered = [torch.empty_like(xg) for _ in range(world)]
+        dist.all_gather(gathered, xg)  # the trivial gather of the sharded result (RCCL over xGMI)
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
