@@ -497,10 +497,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg) rs[reg] = v[reg] + bias;
           if (a.temb) {  // wave-uniform
+            if (a.bs == 1) {
+              // one sample per tile: one time-embedding row for the whole block
+              const float tv = a.temb[(size_t)a.tidx[b0 < a.B ? b0 : 0] * a.temb_stride + nc];
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-              const long long t = a.tidx[outb[mb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h]];
-              rs[reg] += a.temb[(size_t)t * a.temb_stride + nc];
+              for (int reg = 0; reg < 16; ++reg) rs[reg] += tv;
+            } else {
+#pragma unroll
+              for (int reg = 0; reg < 16; ++reg) {
+                const long long t = a.tidx[outb[mb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h]];
+                rs[reg] += a.temb[(size_t)t * a.temb_stride + nc];
+              }
             }
           }
           if (a.resid) {  // wave-uniform

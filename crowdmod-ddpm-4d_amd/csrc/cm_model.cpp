@@ -1465,6 +1465,7 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
   if (check_ready(m, B)) return 1;
   if (!s || !d_past || !opts || !d_out) return fail("null argument");
   if (s->T > TIME_ROWS) return fail("timesteps %d exceed the %d-row time-embedding table (embeddings.py:7)", s->T, TIME_ROWS);
+  if (opts->use_graph) return fail("use_graph is reserved and must be 0");
   if (opts->sampler == CM_SAMPLER_FM_EULER && (opts->fm_steps < 1 || opts->fm_time_max_pos < 1 || opts->fm_time_max_pos > TIME_ROWS))
     return fail("flow-matching sampler needs fm_steps >= 1 and 1 <= fm_time_max_pos <= %d", TIME_ROWS);
   DevGuard g(m->device);
