@@ -45,14 +45,15 @@ def tune_one(grid, channels, nb64, nb128, B, iters):
             continue
         label = f[1]
         ntaps, stride, par, Ci, Co, Zo, Yo, Xo, NB, MB0, bz0, by0, bx0, ks, flags = (int(v) for v in f[2:])
-        if ntaps not in (27, 8) or ks > 1 or (flags & 8):
+        if ntaps not in (27, 8) or (flags & 8):
             continue
         osd = 2 if par else 1
         Z, Y, X = Zo // osd, Yo // osd, Xo // osd
-        if Z * Y * X <= 64:
+        small = Z * Y * X <= 64                       # K-split layers: the timing includes the combine pass
+        if small != bool(os.environ.get("CM_TUNE_SMALL")):
             continue
         fast = bool(flags & 16)
-        small = bool(flags & 1)
+        smalln = bool(flags & 1)
         max_mb = ({1: 5, 2: 2, 4: 1} if fast else {1: 8, 2: 4, 4: 2})[NB]
         native.check(L.cm_debug_time_conv(h, i, 0, 0, 0, 0, B, iters, C.byref(us)))
         base = us.value
@@ -63,7 +64,7 @@ def tune_one(grid, channels, nb64, nb128, B, iters):
                 for bx in range(1, X + 1):
                     nbox = bz * by * bx
                     MB = (nbox + 31) // 32
-                    if MB > max_mb or (small and MB & (MB - 1)):
+                    if MB > max_mb or (smalln and MB & (MB - 1)):
                         continue
                     tiles = -(-Z // bz) * -(-Y // by) * -(-X // bx)
                     if vox / (tiles * 32.0 * MB) < 0.6:
