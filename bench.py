@@ -186,10 +186,10 @@ def main():
             "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": hbm_traffic(),
             "launches": int(cnt[0]), "avg_launch_us": ms[0] * 1e3 / max(1, cnt[0]),
-            "measured_with": "second run of the same K steps with HIP events around every launch on its launch stream; "
-                             "that run issues whole-batch launches on one stream (the timed run interleaves two "
-                             "half-batch lanes, which makes per-launch durations overlap) -- compare "
-                             "profiles/round1_kernel_stats_lanes1.csv (CM_LANES=1 rocprofv3 trace of this command)",
+            "measured_with": "second run of the same K steps, same launch configuration, with HIP events around every "
+                             "launch on its launch stream (events inside the timed run would add ~1.5 us per "
+                             "launch to `value`); rocprofv3 --kernel-trace --stats of this command: "
+                             "profiles/round1_kernel_stats.csv",
             "algorithmic_gflop_per_launch": conv3_flops / max(1, cnt[0]) / 1e9,
             "class_ms_per_step": {k: ms[i] / a.steps for i, k in enumerate(
                 ["conv3x3x3", "conv1x1x1_gemm", "groupnorm_stats", "attention_core", "elementwise"]) },

@@ -1484,11 +1484,13 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
   const int last = s->T - 1;
   float beta_t = s->tab[CM_TAB_BETA][last], sab_t = s->tab[CM_TAB_SQRT_ALPHA_BAR][last],
         s1m_t = s->tab[CM_TAB_SQRT_ONE_MINUS_ALPHA_BAR][last];
-  // Two-way batch interleave: the chains are independent, so the batch is cut in two halves
-  // that run the whole step sequence on two streams.  Kernels of the two lanes overlap on the
-  // GPU -- the ramp-up / tail of one lane's launch is filled by the other lane's workgroups
-  // and their load / MFMA / store phases fall out of step -- with bit-identical results.
-  static const int want_lanes = getenv("CM_LANES") ? atoi(getenv("CM_LANES")) : 2;
+  // Optional batch interleave (CM_LANES=2): the chains are independent, so the batch can be cut in
+  // halves that run the whole step sequence on separate streams, with bit-identical results; the
+  // ramp-up / tail of one lane's launch is filled by the other lane's workgroups.  It was worth +7 %
+  // while the small kernels were latency chains and is worth ~1.5 % now, so whole-batch launches on one
+  // stream are the default: one launch configuration for the timed run, the per-launch HIP-event
+  // figures and the rocprofv3 trace.
+  static const int want_lanes = getenv("CM_LANES") ? atoi(getenv("CM_LANES")) : 1;
   int lanes = std::max(1, std::min(4, want_lanes));
   if (B < 8 * lanes || m->profile || stream) lanes = 1;
   int Bl[4], off[4];
