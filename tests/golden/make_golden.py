@@ -342,6 +342,57 @@ def gen_train(out):
     print("train loss", float(loss), "second step", float(loss2))
 
 
+def gen_train_full(out):
+    """Training step of the FULL-width model (base 32, ATC grid 12x36, B = 2): loss and the gradient norm of
+    every trainable tensor -- exercises the 32-channel-chunk kernels, the K-split quarter-resolution layers and
+    the parity-form upsample convs of the backward pass, which the narrow model does not reach."""
+    import torch.nn as nn
+    from models.backbones import layers as RL
+    from models.diffusion.forward import ForwardSampler
+    C, B = 3, 2
+    H, W = FULL_GRIDS["atc"]
+    P, F = 5, 3
+    cfg = full_cfg(C)
+    params = spec.init_params(cfg, SEED_W)
+    net = ref_unet(cfg, params).train()
+    past, fut = synth_inputs(B, C, H, W, P, F, "trainfull")
+    eps = prng.normal(SEED_X, "trainfull/eps", fut.size).reshape(fut.shape)
+    t = np.array([17, 803], dtype=np.int64)
+
+    class FixedDrop(nn.Module):
+        def __init__(self, mask):
+            super().__init__()
+            self.mask = mask
+
+        def forward(self, x):
+            return x * self.mask[:, :, None, None, None]
+
+    for name, mod in net.named_modules():
+        if isinstance(mod, RL.ResnetBlock):
+            u = prng.uniform_pm1(SEED_X, f"dropfull/{name}", B * mod.out_channels).reshape(B, mod.out_channels)
+            keep = ((u * 0.5 + 0.5) >= 0.1).astype(np.float32) / np.float32(0.9)
+            mod.dropout = FixedDrop(torch.from_numpy(keep))
+    fs = ForwardSampler(timesteps=1000, scale=0.5)
+    o = torch.randn_like
+    torch.randn_like = lambda x, **kw: torch.from_numpy(eps.copy())
+    try:
+        xt, e = fs(torch.from_numpy(fut), torch.from_numpy(t))
+    finally:
+        torch.randn_like = o
+    pred = net(xt, torch.from_numpy(t), torch.from_numpy(past))
+    loss = torch.nn.functional.mse_loss(pred, e)
+    loss.backward()
+    d = {"t": t, "loss": np.float32(loss.item())}
+    for name, prm in net.named_parameters():
+        if prm.grad is not None:
+            d[f"gnorm/{name}"] = np.float32(prm.grad.norm().item())
+    for k in ("decoder_blocks.5.upsample.1.weight", "bottleneck_blocks.0.conv_1.weight"):
+        g = dict(net.named_parameters())[k].grad.numpy()
+        d[f"gslice/{k}"] = g[:4, :4].copy()      # a 4 x 4 x 3 x 3 x 3 corner of two large gradients
+    np.savez_compressed(os.path.join(out, "train_full.npz"), **d)
+    print("train_full loss", float(loss.item()), "tensors", len(d) - 2)
+
+
 def gen_fm(out):
     """Flow matching on the UNet backbone (models/flow_matching/flow_matching.py): the reference's own
     FM_model.sampling_with_euler with x_0 injected (torch.randn patched) on the narrow model, and one
@@ -444,7 +495,7 @@ def gen_metrics(out):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="schedule,ops,fwd,loop,train,fm,metrics")
+    ap.add_argument("--only", default="schedule,ops,fwd,loop,train,train_full,fm,metrics")
     ap.add_argument("--out", default=HERE)
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -457,6 +508,8 @@ def main():
         gen_fwd(a.out)
     if "train" in todo:
         gen_train(a.out)
+    if "train_full" in todo:
+        gen_train_full(a.out)
     if "fm" in todo:
         gen_fm(a.out)
     if "metrics" in todo:

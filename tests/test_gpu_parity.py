@@ -480,3 +480,42 @@ def test_frame_metrics_vs_reference_tables():
     # total variation: the reference sums |diff| in float32 (pairwise), the device in double
     np.testing.assert_allclose(mg.data_dict["TV_OVER_TIME"], g["TV_OVER_TIME"], rtol=0, atol=2e-3, err_msg="TV")
     assert np.isnan(g["MASK_PSNR_OVER_TIME"]).any()
+
+
+@pytest.mark.gpu
+def test_training_backward_full_width_model_vs_reference():
+    """The same training step on the FULL-width model (base 32, ATC 12x36, B = 2): the 32-channel-chunk register-ring
+    kernels, K-split quarter-resolution layers, parity-form upsample convs and 128-wide attention of the backward
+    pass against the reference's autograd: loss, all 168 gradient norms, two gradient corners."""
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    from crowdmod_ddpm_4d_amd.unet import UNet
+    g = load("train_full.npz")
+    C_, B = 3, 2
+    H, W = FULL_GRIDS["atc"]
+    ucfg = full_cfg(C_)
+    net = UNet(input_channels=C_, output_channels=C_, num_res_blocks=1, base_channels=32, base_channels_multiples=(1, 2, 4),
+               apply_attention=(False, False, True), dropout_rate=0.1, time_multiple=4, condition="Past", max_batch=B)
+    net.load_state_dict(spec.init_params(ucfg, SEED_W))
+    past, fut = synth_inputs(B, C_, H, W, 5, 3, "trainfull")
+    eps = prng.normal(7, "trainfull/eps", fut.size).reshape(fut.shape)
+    masks = {}
+    for blk in spec.make_plan(ucfg).res_blocks():
+        u = prng.uniform_pm1(7, f"dropfull/{blk.prefix}", B * blk.cout).reshape(B, blk.cout)
+        masks[blk.prefix] = ((u * 0.5 + 0.5) >= 0.1).astype(np.float32) / np.float32(0.9)
+    net.ensure(H, W, 5, 3, B)
+    net.train_init(lr=5e-5, betas=(0.5, 0.999), weight_decay=0.003)
+    sampler = DDPM(timesteps=1000, scale=0.5)
+    loss = net.train_step(sampler._handle, fut, past, g["t"], eps, drop_masks=masks, apply_update=False)
+    assert abs(loss - float(g["loss"])) <= 1e-5 * max(1.0, float(g["loss"]))
+    n = 0
+    for key in g.files:
+        if key.startswith("gnorm/"):
+            name, ref = key[6:], float(g[key])
+            got = float(np.sqrt((net.grad(name).astype(np.float64) ** 2).sum()))
+            assert abs(got - ref) <= 1e-3 * ref + 2e-7, (name, got, ref)
+            n += 1
+        if key.startswith("gslice/"):
+            ref = g[key]
+            got = net.grad(key[7:])[:4, :4]
+            assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-8, key
+    assert n == 168
