@@ -159,7 +159,8 @@ hipError_t launch_wgrad(const ConvArgs &a, int MB, const float *dy, int dy_cs, f
                         hipStream_t st);
 hipError_t launch_wgrad_reduce(const float *part, int G, int ncb, int nkb, int ntaps, int Co, int Ci, float *dW,
                                hipStream_t st);
-hipError_t launch_voxel_sum(const float *x, int B, int V, int C, int cs, float *out, int ostride, hipStream_t st);
+hipError_t launch_voxel_sum(const float *x, int B, int V, int C, int cs, float *out, int ostride,
+                            float *scratch /* [16][B][ostride] */, hipStream_t st);
 hipError_t launch_batch_sum(const float *in, int B, int C, int stride, float *out, int accumulate, hipStream_t st);
 struct GnbArgs {
   const float *x0; const float *x1; int C0, C1;  // forward inputs (channels-last)
@@ -197,5 +198,7 @@ hipError_t launch_time_bwd(const TimeBwdArgs &a, hipStream_t st);
 hipError_t launch_adam(float *p, const float *g, float *m, float *v, long long n, float lr, float b1, float b2,
                        float eps, float wd, int step, hipStream_t st);
 hipError_t launch_gather_pack(const float *W, const int *idx, int nk, float *packed, long long n, hipStream_t st);
+struct PackJob { float *dst; const int *idx; long long start; int nk; int pad; };
+hipError_t launch_gather_pack_jobs(const float *W, const PackJob *jobs, int njobs, long long total, hipStream_t st);
 
 }  // namespace cm

@@ -214,28 +214,49 @@ hipError_t launch_wgrad_reduce(const float *part, int G, int ncb, int nkb, int n
 // grid B, 256 threads, fixed summation order.
 // --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void voxel_sum_kernel(const float *__restrict__ x, int V, int C, int cs,
-                                                        float *__restrict__ out, int ostride) {
+                                                        float *__restrict__ part, int ostride, int B, int S) {
   __shared__ float sh[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, sl = blockIdx.z, tid = threadIdx.x;
   const int c = blockIdx.y * 32 + (tid & 31), vl = tid >> 5;  // 8 voxel lanes
+  const int vs = (V + S - 1) / S, v0 = sl * vs, v1 = min(V, v0 + vs);
   float s0 = 0.f, s1 = 0.f;
   if (c < C) {
     const float *p = x + (size_t)b * V * cs + c;
-    int v = vl;
-    for (; v + 8 < V; v += 16) { s0 += p[(size_t)v * cs]; s1 += p[(size_t)(v + 8) * cs]; }
-    if (v < V) s0 += p[(size_t)v * cs];
+    int v = v0 + vl;
+    for (; v + 8 < v1; v += 16) { s0 += p[(size_t)v * cs]; s1 += p[(size_t)(v + 8) * cs]; }
+    if (v < v1) s0 += p[(size_t)v * cs];
   }
   sh[tid] = s0 + s1;
   __syncthreads();
   if (tid < 32 && c < C) {
     float t = 0.f;
     for (int l = 0; l < 8; ++l) t += sh[l * 32 + tid];
-    out[(size_t)b * ostride + c] = t;
+    part[((size_t)sl * B + b) * ostride + c] = t;
   }
 }
 
-hipError_t launch_voxel_sum(const float *x, int B, int V, int C, int cs, float *out, int ostride, hipStream_t st) {
-  hipLaunchKernelGGL(voxel_sum_kernel, dim3(B, (C + 31) / 32), dim3(256), 0, st, x, V, C, cs, out, ostride);
+// out[b][c] = sum_s part[s][b][c]  (fixed order)
+__global__ void slice_sum_kernel(const float *__restrict__ part, int S, int B, int C, int stride, float *__restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  float t = 0.f;
+  for (int s = 0; s < S; ++s) t += part[((size_t)s * B + b) * stride + c];
+  out[(size_t)b * stride + c] = t;
+}
+
+hipError_t launch_voxel_sum(const float *x, int B, int V, int C, int cs, float *out, int ostride, float *scratch,
+                            hipStream_t st) {
+  // enough workgroups for the chip: voxel slices when (samples x channel blocks) alone are too few
+  const int blocks = B * ((C + 31) / 32);
+  int S = 1;
+  while (S < 16 && blocks * S < 1024 && V / (S * 2) >= 64) S *= 2;
+  if (S == 1) {
+    hipLaunchKernelGGL(voxel_sum_kernel, dim3(B, (C + 31) / 32, 1), dim3(256), 0, st, x, V, C, cs, out, ostride, B, 1);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(voxel_sum_kernel, dim3(B, (C + 31) / 32, S), dim3(256), 0, st, x, V, C, cs, scratch, ostride, B, S);
+  hipLaunchKernelGGL(slice_sum_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, scratch, S, B, C, ostride, out);
   return hipGetLastError();
 }
 
@@ -699,6 +720,32 @@ __global__ void gather_pack_kernel(const float *__restrict__ W, const int *__res
     if (j >= 0) s += W[j];
   }
   packed[i] = s;
+}
+
+// All re-packs of one optimizer step in ONE launch: job j covers the global element range
+// [start[j], start[j+1]); a thread finds its job by bisection over the (few hundred) starts.
+__global__ void gather_pack_jobs_kernel(const float *__restrict__ W, const PackJob *__restrict__ jobs, int njobs,
+                                        long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].start <= i) lo = mid; else hi = mid - 1;
+  }
+  const PackJob jb = jobs[lo];
+  const long long e = i - jb.start;
+  float s = 0.f;
+  for (int k = 0; k < jb.nk; ++k) {
+    const int j = jb.idx[e * jb.nk + k];
+    if (j >= 0) s += W[j];
+  }
+  jb.dst[e] = s;
+}
+
+hipError_t launch_gather_pack_jobs(const float *W, const PackJob *jobs, int njobs, long long total, hipStream_t st) {
+  hipLaunchKernelGGL(gather_pack_jobs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, jobs, njobs, total);
+  return hipGetLastError();
 }
 
 hipError_t launch_gather_pack(const float *W, const int *idx, int nk, float *packed, long long n, hipStream_t st) {
