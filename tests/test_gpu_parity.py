@@ -519,3 +519,41 @@ def test_training_backward_full_width_model_vs_reference():
             got = net.grad(key[7:])[:4, :4]
             assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-8, key
     assert n == 168
+
+
+@pytest.mark.gpu
+def test_abi_rejects_bad_arguments_loudly():
+    """Error behaviour of the C ABI on the device: every misuse returns non-zero with a message (raised as
+    NativeError by the ctypes layer) instead of computing something else."""
+    from crowdmod_ddpm_4d_amd import native
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    from crowdmod_ddpm_4d_amd.unet import UNet
+    C_ = 3
+    net = UNet(input_channels=C_, output_channels=C_, num_res_blocks=1, base_channels=8, base_channels_multiples=(1, 2, 4),
+               apply_attention=(False, False, True), max_batch=2)
+    net.load_state_dict(spec.init_params(narrow_cfg(C_), SEED_W))
+    past, fut = synth_inputs(2, C_, NARROW["H"], NARROW["W"], NARROW["P"], NARROW["F"], "abi")
+    out = net(fut, np.array([3, 5]), past)
+    assert np.isfinite(out).all()
+    L, h = native.lib(), net._handle
+    with pytest.raises(native.NativeError, match="timestep"):
+        net(fut, np.array([3, 1000]), past)                       # the table has 1000 rows (embeddings.py:7)
+    d = native.DeviceBuffer(fut.nbytes)
+    with pytest.raises(native.NativeError, match="batch"):
+        native.check(L.cm_unet_forward(h, d.ptr, d.ptr, d.ptr, d.ptr, 3, None))   # > max_batch
+    with pytest.raises(native.NativeError, match="null"):
+        native.check(L.cm_unet_forward(h, None, d.ptr, d.ptr, d.ptr, 2, None))
+    s = DDPM(timesteps=50, scale=0.5)
+    o = native.cm_sample_opts()
+    o.use_graph = 1
+    with pytest.raises(native.NativeError, match="use_graph"):
+        native.check(L.cm_sample_loop(h, s._handle, d.ptr, None, None, C.byref(o), d.ptr, None, 2, None))
+    o = native.cm_sample_opts()
+    o.sampler = native.SAMPLER_FM_EULER
+    o.fm_steps, o.fm_time_max_pos = 4, 2000
+    with pytest.raises(native.NativeError, match="flow-matching"):
+        native.check(L.cm_sample_loop(h, s._handle, d.ptr, None, None, C.byref(o), d.ptr, None, 2, None))
+    with pytest.raises(native.NativeError, match="cm_train_init"):
+        native.check(L.cm_train_apply(h, None))
+    with pytest.raises(ValueError):
+        net(fut[:, :2], np.array([1, 2]), past)                   # channel mismatch is caught before the call
