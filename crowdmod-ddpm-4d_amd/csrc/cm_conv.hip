@@ -37,8 +37,12 @@ __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_r
 // FAST = 0: generic step loop; 27 / 8: CK == 32 with that many taps (register weight ring);
 // 127: the 27-tap ring path plus the fused 1x1x1 skip chunks (its own variant so that the plain
 // kernels do not carry its registers)
-template <int MB, int NB, int FAST>
+// BZ x BY x BX != 0: the output box is a compile-time constant (stride 1, one sample per tile, no
+// parity / upsampling): halo extents, LDS strides and every table entry fold into immediates, which
+// removes the table loads and most of the integer / scalar-spill traffic of the prologue and staging.
+template <int MB, int NB, int FAST, int BZ = 0, int BY = 0, int BX = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr bool SPEC = BZ != 0;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TM = 32 * MB;
   constexpr int TN = 32 * NB;
@@ -72,23 +76,44 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       for (int i = 0; i < a.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
     }
   }
-  const int b0 = ts * a.bs, z0 = tz * a.bz, y0 = ty * a.by, x0 = tx * a.bx;
+  const int a_bs = SPEC ? 1 : a.bs, a_bz = SPEC ? BZ : a.bz, a_by = SPEC ? BY : a.by, a_bx = SPEC ? BX : a.bx;
+  const int a_stride = SPEC ? 1 : a.stride, a_par = SPEC ? 0 : a.par, a_ups = SPEC ? 0 : a.ups, a_td = SPEC ? 3 : a.td;
+  const int b0 = ts * a_bs, z0 = tz * a_bz, y0 = ty * a_by, x0 = tx * a_bx;
 
   // parity class of an upsampled conv: out voxel u = 2i + p reads source voxels i + e + p - 1,
   // e in {0,1}, with the taps that fall on the same source voxel pre-summed on the host
-  const int par = a.par ? (int)blockIdx.z : 0;
+  const int par = a_par ? (int)blockIdx.z : 0;
   const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
-  const int os = a.par ? 2 : 1;
-  const int pad = (a.td == 3) ? 1 : 0;
-  const int td = a.td;
-  const int HZ = (a.bz - 1) * a.stride + td;
-  const int HY = (a.by - 1) * a.stride + td;
-  const int HX = (a.bx - 1) * a.stride + td;
+  const int os = a_par ? 2 : 1;
+  const int pad = (a_td == 3) ? 1 : 0;
+  const int td = a_td;
+  const int HZ = (a_bz - 1) * a_stride + td;
+  const int HY = (a_by - 1) * a_stride + td;
+  const int HX = (a_bx - 1) * a_stride + td;
   const int HV1 = HZ * HY * HX;
-  const int HV = a.bs * HV1;
+  const int HV = a_bs * HV1;
   const int HVp = (HV + 3) & ~3;
-  const int S = a.CK + 4;
-  const int nbox = a.bs * a.bz * a.by * a.bx;
+  const int S = (SPEC ? 32 : a.CK) + 4;
+  const int nbox = a_bs * a_bz * a_by * a_bx;
+  // packed row / halo coordinates: host tables in general, arithmetic (constant divisors) when specialised
+  auto mtab_at = [&](int m) -> int {
+    if constexpr (SPEC) {
+      if (m >= BZ * BY * BX) return -1;
+      const int z = m / (BY * BX), rem = m - z * (BY * BX), y = rem / BX, x = rem - y * BX;
+      return (z << 18) | (y << 9) | x;
+    } else {
+      return a.mtab[m];
+    }
+  };
+  auto hvtab_at = [&](int hv) -> int {
+    if constexpr (SPEC) {
+      constexpr int cHY = BY + 2, cHX = BX + 2;
+      const int hz = hv / (cHY * cHX), rem = hv - hz * (cHY * cHX), hy = rem / cHX, hx = rem - hy * cHX;
+      return (hz << 18) | (hy << 9) | hx;
+    } else {
+      return a.hvtab[hv];
+    }
+  };
 
   int *outoff = reinterpret_cast<int *>(lds);  // [TM] output voxel index or -1
   int *outb = outoff + TM;                     // [TM] sample index of the row
@@ -100,10 +125,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   // unconditionally and back to back, and decoded branch-free: a load behind a divergent branch
   // costs its own memory round trip (~1 us under load), and there were six of them in a row.
   static_assert(TM <= 256, "one row-table pass");
-  const int pk_row = a.mtab[tid < TM ? tid : TM - 1];
+  const int pk_row = mtab_at(tid < TM ? tid : TM - 1);
   int pk_ab[MB];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) pk_ab[mb] = a.mtab[mb * 32 + r];
+  for (int mb = 0; mb < MB; ++mb) pk_ab[mb] = mtab_at(mb * 32 + r);
   {
     const int pk = pk_row;
     const bool v = pk >= 0;
@@ -114,9 +139,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int bb = (v && b < a.B) ? b : 0;
     if (tid < TM) { outoff[tid] = off; outb[tid] = bb; }
   }
-  const int Zc = a.Zs << a.ups, Yc = a.Ys << a.ups, Xc = a.Xs << a.ups;
-  const int cz0 = z0 * a.stride + (a.par ? pz - 1 : -pad), cy0 = y0 * a.stride + (a.par ? py - 1 : -pad),
-            cx0 = x0 * a.stride + (a.par ? px - 1 : -pad);
+  const int Zc = a.Zs << a_ups, Yc = a.Ys << a_ups, Xc = a.Xs << a_ups;
+  const int cz0 = z0 * a_stride + (a_par ? pz - 1 : -pad), cy0 = y0 * a_stride + (a_par ? py - 1 : -pad),
+            cx0 = x0 * a_stride + (a_par ? px - 1 : -pad);
 
   // ---- per-lane LDS row base of each of this wave's MB row blocks -----------
   int abase[MB];
@@ -124,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   for (int mb = 0; mb < MB; ++mb) {
     const int pk = pk_ab[mb] >= 0 ? pk_ab[mb] : 0;
     const int x = pk & 511, y = (pk >> 9) & 511, z = (pk >> 18) & 255, s = pk >> 26;
-    const int hv = ((s * HZ + z * a.stride) * HY + y * a.stride) * HX + x * a.stride;
+    const int hv = ((s * HZ + z * a_stride) * HY + y * a_stride) * HX + x * a_stride;
     abase[mb] = hv * S + 4 * h;
   }
 
@@ -136,7 +161,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.0f;
 
-  const int K4 = a.CK >> 2, K8 = a.CK >> 3;
+  const int a_CK = SPEC ? 32 : a.CK;
+  const int K4 = a_CK >> 2, K8 = a_CK >> 3;
   const int nsteps = a.ntaps * K8;
   const int nchunks = a.nch0 + a.nch1;
   const int Ctot = a.C0 + a.C1;
@@ -173,13 +199,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   // loads back to back (one memory latency per chunk instead of one per dependent step --
   // a global load costs 1.5-2 us under load on this part, profiles/round1_notes.md).
   constexpr int NVM = 12;                        // halo float4 per thread (HV <= 384)
-  const bool fstage = fast && a.bs == 1 && HV <= NVM * 32;
+  const bool fstage = fast && a_bs == 1 && HV <= NVM * 32;
   int soff[NVM];
   unsigned okmask = 0;
   // Row mode: a thread owns one or two whole x-rows of the halo box (row = hz * HY + hy), so the
   // coordinate decode and the bounds of z / y happen once per row instead of once per voxel.
   const int HR = HZ * HY, RJ = (HR + 31) >> 5;
-  const bool rowmode = fstage && a.ups == 0 && RJ * HX <= NVM && !(a.dbg & 512);
+  const bool rowmode = fstage && a_ups == 0 && RJ * HX <= NVM && (SPEC || !(a.dbg & 512));
   // slot k of a thread: (row lane j, x) in row mode, voxel v0 + 32 k otherwise
   auto slot_j = [&](int k) { return RJ == 2 ? k / 6 : 0; };
   auto slot_x = [&](int k) { return RJ == 2 ? k % 6 : k; };
@@ -191,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     bool rowok[2];
     int pkr[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) pkr[j] = a.hvtab[min(v0 + 32 * j, HR - 1) * HX];
+    for (int j = 0; j < 2; ++j) pkr[j] = hvtab_at(min(v0 + 32 * j, HR - 1) * HX);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int rr = v0 + 32 * j;
@@ -212,14 +238,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int k = 0; k < NVM; ++k) {
       const int hv = v0 + k * 32;
-      pkk[k] = a.hvtab[hv < HV ? hv : HV - 1];
+      pkk[k] = hvtab_at(hv < HV ? hv : HV - 1);
     }
 #pragma unroll
     for (int k = 0; k < NVM; ++k) {
       const int hv = v0 + k * 32;
       const int cx = cx0 + (pkk[k] & 511), cy = cy0 + ((pkk[k] >> 9) & 511), cz = cz0 + ((pkk[k] >> 18) & 255);
       const bool ok = hv < HV && b0 < a.B && cz >= 0 && cz < Zc && cy >= 0 && cy < Yc && cx >= 0 && cx < Xc;
-      soff[k] = ok ? ((b0 * a.Zs + (cz >> a.ups)) * a.Ys + (cy >> a.ups)) * a.Xs + (cx >> a.ups) : 0;
+      soff[k] = ok ? ((b0 * a.Zs + (cz >> a_ups)) * a.Ys + (cy >> a_ups)) * a.Xs + (cx >> a_ups) : 0;
       okmask |= (ok ? 1u : 0u) << k;
     }
   }
@@ -228,8 +254,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   for (int ch = ch0; ch < ch1; ++ch) {
     const float *src;
     int Cs, c0, cg0;
-    if (ch < a.nch0) { src = a.src0; Cs = a.C0; c0 = ch * a.CK; cg0 = c0; }
-    else { src = a.src1; Cs = a.C1; c0 = (ch - a.nch0) * a.CK; cg0 = a.C0 + c0; }
+    if (ch < a.nch0) { src = a.src0; Cs = a.C0; c0 = ch * a_CK; cg0 = c0; }
+    else { src = a.src1; Cs = a.C1; c0 = (ch - a.nch0) * a_CK; cg0 = a.C0 + c0; }
     __syncthreads();  // tables ready (first pass) / previous chunk fully consumed
     // ---- stage the halo tile of this channel chunk ---------------------------
     // (loads are issued in batches of SU so that their latencies overlap)
@@ -241,9 +267,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     // GroupNorm scale / shift of this thread's channel quad: one pair per chunk when the tile
     // holds a single sample (the common case), looked up per voxel otherwise
     f32x4 sc1 = {1.f, 1.f, 1.f, 1.f}, sh1 = {0.f, 0.f, 0.f, 0.f}, pm1 = {1.f, 1.f, 1.f, 1.f};
-    if (a.pm && a.bs == 1)
+    if (a.pm && a_bs == 1)
       pm1 = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)(b0 < a.B ? b0 : 0) * a.pm_stride + cg0 + 4 * q4);
-    if (a.gn && a.bs == 1) {
+    if (a.gn && a_bs == 1) {
       const float *g = a.gn + (size_t)(b0 < a.B ? b0 : 0) * 2 * Ctot + cg0 + 4 * q4;
       sc1 = *reinterpret_cast<const f32x4 *>(g);
       sh1 = *reinterpret_cast<const f32x4 *>(g + Ctot);
@@ -268,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         }
       }
     }
-    for (int hv0 = v0; hv0 < HV && !(a.dbg & 1) && !fstage; hv0 += vstep * SU) {
+    for (int hv0 = v0; !SPEC && hv0 < HV && !(a.dbg & 1) && !fstage; hv0 += vstep * SU) {
       int pk[SU];
       f32x4 v[SU];
       int bbv[SU];
@@ -294,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         f32x4 w = v[u];
         if (a.gn && !(a.dbg & 128)) {
           f32x4 sc = sc1, sh = sh1;
-          if (a.bs != 1) {
+          if (a_bs != 1) {
             const float *g = a.gn + (size_t)bbv[u] * 2 * Ctot + cg0 + 4 * q4;
             sc = *reinterpret_cast<const f32x4 *>(g);
             sh = *reinterpret_cast<const f32x4 *>(g + Ctot);
@@ -304,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         }
         if (a.pm) {
           f32x4 pmv = pm1;
-          if (a.bs != 1) pmv = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)bbv[u] * a.pm_stride + cg0 + 4 * q4);
+          if (a_bs != 1) pmv = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)bbv[u] * a.pm_stride + cg0 + 4 * q4);
           w = w * pmv;
         }
         if (!ok[u]) w = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -497,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg) rs[reg] = v[reg] + bias;
           if (a.temb) {  // wave-uniform
-            if (a.bs == 1) {
+            if (a_bs == 1) {
               // one sample per tile: one time-embedding row for the whole block
               const float tv = a.temb[(size_t)a.tidx[b0 < a.B ? b0 : 0] * a.temb_stride + nc];
 #pragma unroll
@@ -650,21 +676,33 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
   dim3 grid((unsigned)(a.nts * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + TN - 1) / TN),
             a.par ? 8u : (a.ks > 1 ? (unsigned)a.ks : 1u));
   const int fastk = (a.CK == 32 && (a.ntaps == 27 || a.ntaps == 8)) ? a.ntaps : 0;
-#define CM_LAUNCH(m, n, f)                                                                       \
+#define CM_LAUNCH_T(KERNEL, m, n, f)                                                             \
   {                                                                                              \
     static bool attr_set[64] = {false};                                                          \
     int dev = 0;                                                                                 \
     (void)hipGetDevice(&dev);                                                                    \
     if (!attr_set[dev & 63]) {                                                                   \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<m, n, f>), \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL),                 \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       if (e != hipSuccess) return e;                                                             \
       attr_set[dev & 63] = true;                                                                 \
     }                                                                                            \
-    hipLaunchKernelGGL((conv_mfma_kernel<m, n, f>), grid, dim3(256), lds, st, a);                \
+    hipLaunchKernelGGL(KERNEL, grid, dim3(256), lds, st, a);                                     \
     if (dbg & 8) conv_dbg_report(a, m, n, f, grid, dbgbuf, st);                                  \
     return hipGetLastError();                                                                    \
   }
+#define CM_LAUNCH(m, n, f) CM_LAUNCH_T((conv_mfma_kernel<m, n, f>), m, n, f)
+  // shape-specialised instantiations for the hot tile shapes of the reference grids
+  const bool specok = fastk == 27 && a.bs == 1 && a.stride == 1 && !a.par && !a.ups && a.td == 3 && !(dbg & 2048);
+#define CM_SPEC(m, n, z, y, x)                                                     \
+  if (specok && MB == m && NB == n && a.bz == z && a.by == y && a.bx == x) {       \
+    if (a.s2w) CM_LAUNCH_T((conv_mfma_kernel<m, n, 127, z, y, x>), m, n, 127)      \
+    CM_LAUNCH_T((conv_mfma_kernel<m, n, 27, z, y, x>), m, n, 27)                   \
+  }
+  CM_SPEC(4, 1, 8, 4, 4)
+  CM_SPEC(2, 2, 2, 3, 9)
+  CM_SPEC(2, 2, 2, 6, 5)
+#undef CM_SPEC
 #define X(m, n)                                    \
   if (MB == m && NB == n) {                        \
     if (fastk == 27 && a.s2w) CM_LAUNCH(m, n, 127) \
