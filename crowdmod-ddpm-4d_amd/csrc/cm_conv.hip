@@ -40,9 +40,12 @@ __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_r
 // BZ x BY x BX != 0: the output box is a compile-time constant (stride 1, one sample per tile, no
 // parity / upsampling): halo extents, LDS strides and every table entry fold into immediates, which
 // removes the table loads and most of the integer / scalar-spill traffic of the prologue and staging.
-template <int MB, int NB, int FAST, int BZ = 0, int BY = 0, int BX = 0>
+// FAST = 8 specialisations are the parity (upsample) form, STR = 2 the strided 27-tap conv.
+template <int MB, int NB, int FAST, int BZ = 0, int BY = 0, int BX = 0, int STR = 1>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr bool SPEC = BZ != 0;
+  constexpr bool SPAR = SPEC && (FAST % 100) == 8;   // specialised parity form: 2 taps per dimension
+  constexpr int STD = SPAR ? 2 : 3;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TM = 32 * MB;
   constexpr int TN = 32 * NB;
@@ -77,7 +80,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     }
   }
   const int a_bs = SPEC ? 1 : a.bs, a_bz = SPEC ? BZ : a.bz, a_by = SPEC ? BY : a.by, a_bx = SPEC ? BX : a.bx;
-  const int a_stride = SPEC ? 1 : a.stride, a_par = SPEC ? 0 : a.par, a_ups = SPEC ? 0 : a.ups, a_td = SPEC ? 3 : a.td;
+  const int a_stride = SPEC ? STR : a.stride, a_par = SPEC ? (SPAR ? 1 : 0) : a.par, a_ups = SPEC ? 0 : a.ups,
+            a_td = SPEC ? STD : a.td;
   const int b0 = ts * a_bs, z0 = tz * a_bz, y0 = ty * a_by, x0 = tx * a_bx;
 
   // parity class of an upsampled conv: out voxel u = 2i + p reads source voxels i + e + p - 1,
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   };
   auto hvtab_at = [&](int hv) -> int {
     if constexpr (SPEC) {
-      constexpr int cHY = BY + 2, cHX = BX + 2;
+      constexpr int cHY = (BY - 1) * STR + STD, cHX = (BX - 1) * STR + STD;
       const int hz = hv / (cHY * cHX), rem = hv - hz * (cHY * cHX), hy = rem / cHX, hx = rem - hy * cHX;
       return (hz << 18) | (hy << 9) | hx;
     } else {
@@ -294,7 +298,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         }
       }
     }
-    for (int hv0 = v0; !SPEC && hv0 < HV && !(a.dbg & 1) && !fstage; hv0 += vstep * SU) {
+    // (dead code in a specialisation whose halo box fits the fast staging)
+    constexpr bool SPEC_FSTAGE = SPEC && ((BZ - 1) * STR + STD) * ((BY - 1) * STR + STD) * ((BX - 1) * STR + STD) <= NVM * 32;
+    for (int hv0 = v0; !SPEC_FSTAGE && hv0 < HV && !(a.dbg & 1) && !fstage; hv0 += vstep * SU) {
       int pk[SU];
       f32x4 v[SU];
       int bbv[SU];
@@ -703,6 +709,21 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
   CM_SPEC(2, 2, 2, 3, 9)
   CM_SPEC(2, 2, 2, 6, 5)
 #undef CM_SPEC
+  // parity (upsample) form and stride-2 convs
+  const bool specpar = fastk == 8 && a.bs == 1 && a.stride == 1 && a.par && !a.ups && a.td == 2 && !(dbg & 2048);
+  const bool specs2 = fastk == 27 && a.bs == 1 && a.stride == 2 && !a.par && !a.ups && a.td == 3 && !a.s2w && !(dbg & 2048);
+#define CM_SPEC_PAR(m, n, z, y, x)                                                 \
+  if (specpar && MB == m && NB == n && a.bz == z && a.by == y && a.bx == x)        \
+    CM_LAUNCH_T((conv_mfma_kernel<m, n, 8, z, y, x>), m, n, 8)
+#define CM_SPEC_S2(m, n, z, y, x)                                                  \
+  if (specs2 && MB == m && NB == n && a.bz == z && a.by == y && a.bx == x)         \
+    CM_LAUNCH_T((conv_mfma_kernel<m, n, 27, z, y, x, 2>), m, n, 27)
+  CM_SPEC_PAR(5, 1, 4, 6, 6)
+  CM_SPEC_PAR(2, 2, 2, 3, 9)
+  CM_SPEC_S2(1, 1, 4, 2, 4)
+  CM_SPEC_S2(1, 2, 1, 3, 9)
+#undef CM_SPEC_PAR
+#undef CM_SPEC_S2
 #define X(m, n)                                    \
   if (MB == m && NB == n) {                        \
     if (fastk == 27 && a.s2w) CM_LAUNCH(m, n, 127) \
