@@ -705,9 +705,15 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
     if (a.s2w) CM_LAUNCH_T((conv_mfma_kernel<m, n, 127, z, y, x>), m, n, 127)      \
     CM_LAUNCH_T((conv_mfma_kernel<m, n, 27, z, y, x>), m, n, 27)                   \
   }
-  CM_SPEC(4, 1, 8, 4, 4)
-  CM_SPEC(2, 2, 2, 3, 9)
+  CM_SPEC(4, 1, 8, 4, 4)   // ATC / 2x grid full resolution
+  CM_SPEC(2, 2, 2, 3, 9)   // ATC half and quarter resolution
   CM_SPEC(2, 2, 2, 6, 5)
+  CM_SPEC(1, 2, 2, 3, 5)
+  CM_SPEC(4, 1, 4, 4, 8)   // HERMES-CR-120 / 2x grid
+  CM_SPEC(3, 1, 2, 7, 6)
+  CM_SPEC(2, 2, 2, 7, 4)
+  CM_SPEC(2, 2, 4, 3, 5)
+  CM_SPEC(2, 2, 4, 4, 4)
 #undef CM_SPEC
   // parity (upsample) form and stride-2 convs
   const bool specpar = fastk == 8 && a.bs == 1 && a.stride == 1 && a.par && !a.ups && a.td == 2 && !(dbg & 2048);
@@ -720,8 +726,14 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
     CM_LAUNCH_T((conv_mfma_kernel<m, n, 27, z, y, x, 2>), m, n, 27)
   CM_SPEC_PAR(5, 1, 4, 6, 6)
   CM_SPEC_PAR(2, 2, 2, 3, 9)
+  CM_SPEC_PAR(3, 1, 2, 7, 6)
+  CM_SPEC_PAR(2, 2, 4, 4, 4)
   CM_SPEC_S2(1, 1, 4, 2, 4)
   CM_SPEC_S2(1, 2, 1, 3, 9)
+  CM_SPEC_S2(1, 1, 2, 4, 4)
+  CM_SPEC_S2(1, 1, 2, 7, 2)
+  CM_SPEC_S2(1, 2, 2, 3, 5)
+  CM_SPEC_S2(1, 2, 2, 7, 2)
 #undef CM_SPEC_PAR
 #undef CM_SPEC_S2
 #define X(m, n)                                    \
