@@ -41,8 +41,11 @@ __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_r
 // parity / upsampling): halo extents, LDS strides and every table entry fold into immediates, which
 // removes the table loads and most of the integer / scalar-spill traffic of the prologue and staging.
 // FAST = 8 specialisations are the parity (upsample) form, STR = 2 the strided 27-tap conv.
+#ifndef CM_SPEC_OCC
+#define CM_SPEC_OCC 2
+#endif
 template <int MB, int NB, int FAST, int BZ = 0, int BY = 0, int BX = 0, int STR = 1>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (BZ != 0 && MB * NB <= 4 ? CM_SPEC_OCC : 2)) void conv_mfma_kernel(const ConvArgs a) {
   constexpr bool SPEC = BZ != 0;
   constexpr bool SPAR = SPEC && (FAST % 100) == 8;   // specialised parity form: 2 taps per dimension
   constexpr int STD = SPAR ? 2 : 3;
@@ -202,8 +205,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   // their source offsets are resolved ONCE per workgroup; every chunk then issues all its
   // loads back to back (one memory latency per chunk instead of one per dependent step --
   // a global load costs 1.5-2 us under load on this part, profiles/round1_notes.md).
-  constexpr int NVM = 12;                        // halo float4 per thread (HV <= 384)
-  const bool fstage = fast && a_bs == 1 && HV <= NVM * 32;
+  // halo float4 per thread: 12 (HV <= 384) in general; a specialisation sizes it to its own box
+  constexpr int cHZs = (BZ - 1) * STR + STD, cHYs = (BY - 1) * STR + STD, cHXs = (BX - 1) * STR + STD;
+  constexpr int cRJ = (cHZs * cHYs + 31) / 32;
+  constexpr int NVM = !SPEC ? 12
+                      : (cRJ <= 2 && cRJ * cHXs <= 16 && cRJ * cHXs > 12) ? 16                 // row mode, 13-16 slots
+                      : (cHZs * cHYs * cHXs > 384 && cHZs * cHYs * cHXs <= 512) ? 16 : 12;      // voxel mode up to 512 voxels
+  const bool fstage = fast && a_bs == 1 && (HV <= NVM * 32 || (SPEC && cRJ <= 2 && cRJ * cHXs <= NVM));
   int soff[NVM];
   unsigned okmask = 0;
   // Row mode: a thread owns one or two whole x-rows of the halo box (row = hz * HY + hy), so the
@@ -211,8 +219,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   const int HR = HZ * HY, RJ = (HR + 31) >> 5;
   const bool rowmode = fstage && a_ups == 0 && RJ * HX <= NVM && (SPEC || !(a.dbg & 512));
   // slot k of a thread: (row lane j, x) in row mode, voxel v0 + 32 k otherwise
-  auto slot_j = [&](int k) { return RJ == 2 ? k / 6 : 0; };
-  auto slot_x = [&](int k) { return RJ == 2 ? k % 6 : k; };
+  auto slot_j = [&](int k) { return RJ == 2 ? k / (NVM / 2) : 0; };
+  auto slot_x = [&](int k) { return RJ == 2 ? k % (NVM / 2) : k; };
   auto slot_used = [&](int k) { return rowmode ? (slot_x(k) < HX && slot_j(k) < RJ) : (k * 32 < HV); };
   auto slot_hv = [&](int k) { return rowmode ? (v0 + 32 * slot_j(k)) * HX + slot_x(k) : v0 + k * 32; };
   auto slot_mine = [&](int k) { return rowmode ? (v0 + 32 * slot_j(k) < HR) : (v0 + k * 32 < HV); };
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       }
     }
     // (dead code in a specialisation whose halo box fits the fast staging)
-    constexpr bool SPEC_FSTAGE = SPEC && ((BZ - 1) * STR + STD) * ((BY - 1) * STR + STD) * ((BX - 1) * STR + STD) <= NVM * 32;
+    constexpr bool SPEC_FSTAGE = SPEC && (cHZs * cHYs * cHXs <= NVM * 32 || (cRJ <= 2 && cRJ * cHXs <= NVM));
     for (int hv0 = v0; !SPEC_FSTAGE && hv0 < HV && !(a.dbg & 1) && !fstage; hv0 += vstep * SU) {
       int pk[SU];
       f32x4 v[SU];

@@ -431,7 +431,7 @@ void pick_tile(Op &op, int B) {
   if (const TunedTile *t = find_tuned(a, NB)) {
     const int osdt = a.par ? 2 : 1;
     a.bs = 1; a.bz = t->bz; a.by = t->by; a.bx = t->bx;
-    if (cm::conv_variant_exists(t->MB, NB) && (t->bz * t->by * t->bx + 31) / 32 == t->MB && cm::conv_lds_bytes(a, t->MB, NB) <= 64 * 1024 &&
+    if (cm::conv_variant_exists(t->MB, NB) && (t->bz * t->by * t->bx + 31) / 32 == t->MB && cm::conv_lds_bytes(a, t->MB, NB) <= 80 * 1024 &&
         (!op.small_n || !(t->MB & (t->MB - 1)))) {
       op.MB = t->MB;
       a.ntz = (a.Zo / osdt + a.bz - 1) / a.bz; a.nty = (a.Yo / osdt + a.by - 1) / a.by; a.ntx = (a.Xo / osdt + a.bx - 1) / a.bx;
@@ -1703,7 +1703,7 @@ int cm_debug_time_conv(cm_model *m, int32_t index, int32_t MB, int32_t bz, int32
       a.bs = 1; a.bz = bz; a.by = by; a.bx = bx;
       op.MB = MB;
       a.ntz = (a.Zo / osd + bz - 1) / bz; a.nty = (a.Yo / osd + by - 1) / by; a.ntx = (a.Xo / osd + bx - 1) / bx;
-      if (cm::conv_lds_bytes(a, MB, op.NB) > 64 * 1024) rc = fail("tile needs too much LDS");
+      if (cm::conv_lds_bytes(a, MB, op.NB) > 80 * 1024) rc = fail("tile needs too much LDS");  // two workgroups per CU
       if (!rc && op.small_n && (MB & (MB - 1))) rc = fail("small-N kernel needs a power-of-two MB");
       if (!rc && op.stat_act && a.ntz * a.nty * a.ntx * MB * (a.par ? 8 : 1) > MAX_SLOTS) rc = fail("too many statistics slots");
       if (!rc && cm::conv_halo_voxels(a) > 16384) rc = fail("halo box too large");
