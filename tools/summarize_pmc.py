@@ -11,6 +11,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -47,7 +48,8 @@ for k in sorted(fetch, key=lambda k: -sum(fetch[k]["FETCH_SIZE"])):
     valu_per_mfma = tot("SQ_INSTS_VALU") / tot("SQ_INSTS_MFMA") if s and tot("SQ_INSTS_MFMA") > 0 else float("nan")
     lds_conf = tot("SQ_LDS_BANK_CONFLICT") / max(1.0, tot("SQ_LDS_IDX_ACTIVE")) if s else float("nan")
     rows.append((k, n, fk, wk, hbm, mfma_busy, valu_per_mfma, lds_conf))
-    if "conv_mfma_kernel" in k and (", 27>" in k or ", 127>" in k or ", 8>" in k) or "conv_smalln" in k:
+    m3 = re.search(r"conv_mfma_kernel<\d+, \d+, (\d+)", k)
+    if (m3 and m3.group(1) in ("27", "127", "8")) or "conv_smalln" in k:
         conv_bytes += hbm * n
         conv_n += n
 with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.csv"), "w") as fo:
