@@ -140,6 +140,7 @@ struct cm_schedule {
 };
 
 struct cm_train_state;
+void cm_free_train_state(cm_train_state *t);  // cm_train_host.inc (host-side struct only; device buffers live in allocs)
 struct cm_model {
   cm_unet_config cfg{};
   int device = 0;
@@ -1210,6 +1211,7 @@ int cm_model_destroy(cm_model *m) {
     if (m->ev_join[i]) hipEventDestroy(m->ev_join[i]);
   }
   if (m->ev_fork) hipEventDestroy(m->ev_fork);
+  if (m->train) cm_free_train_state(m->train);
   delete m;
   return 0;
 }
