@@ -18,30 +18,53 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_s(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-template <int NCO>
-__global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvArgs a, const float *__restrict__ wsm, int TM) {
+// BZ x BY x BX != 0: compile-time tile box with 32-channel chunks (the tuned shape of the reference grids):
+// halo extents, strides and the coordinate tables fold into immediates.
+template <int NCO, int BZ = 0, int BY = 0, int BX = 0>
+__global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvArgs a, const float *__restrict__ wsm, int TM_rt) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr bool SPEC = BZ != 0;
+  const int TM = SPEC ? 32 * ((BZ * BY * BX + 31) / 32) : TM_rt;
+  const int a_bz = SPEC ? BZ : a.bz, a_by = SPEC ? BY : a.by, a_bx = SPEC ? BX : a.bx, a_CK = SPEC ? 32 : a.CK;
   const int tid = threadIdx.x;
   int tile = blockIdx.x;
   const int tx = tile % a.ntx; tile /= a.ntx;
   const int ty = tile % a.nty; tile /= a.nty;
   const int tz = tile % a.ntz;
   const int b = tile / a.ntz;
-  const int z0 = tz * a.bz, y0 = ty * a.by, x0 = tx * a.bx;
-  const int HZ = a.bz + 2, HY = a.by + 2, HX = a.bx + 2;
+  const int z0 = tz * a_bz, y0 = ty * a_by, x0 = tx * a_bx;
+  const int HZ = a_bz + 2, HY = a_by + 2, HX = a_bx + 2;
   const int HV = HZ * HY * HX;
-  const int S = a.CK + 4;
+  const int S = a_CK + 4;
+  auto mtab_at = [&](int m) -> int {
+    if constexpr (SPEC) {
+      if (m >= BZ * BY * BX) return -1;
+      const int z = m / (BY * BX), rem = m - z * (BY * BX), y = rem / BX, x = rem - y * BX;
+      return (z << 18) | (y << 9) | x;
+    } else {
+      return a.mtab[m];
+    }
+  };
+  auto hvtab_at = [&](int hv) -> int {
+    if constexpr (SPEC) {
+      constexpr int cHY = BY + 2, cHX = BX + 2;
+      const int hz = hv / (cHY * cHX), rem = hv - hz * (cHY * cHX), hy = rem / cHX, hx = rem - hy * cHX;
+      return (hz << 18) | (hy << 9) | hx;
+    } else {
+      return a.hvtab[hv];
+    }
+  };
   const int Ctot = a.C0 + a.C1;
   const int nchunks = a.nch0 + a.nch1;
   const int NG = 256 / TM;                     // tap groups (threads per output voxel)
 
   float *A = lds;                              // [HV][S]
   float *W = A + (size_t)HV * S;               // [27][CK][NCO]
-  float *red = W + 27 * a.CK * NCO;            // [NG - 1][TM][NCO]
+  float *red = W + 27 * a_CK * NCO;            // [NG - 1][TM][NCO]
 
   // this thread's output voxel
   const int m = tid % TM, grp = tid / TM;
-  const int pk = a.mtab[m];
+  const int pk = mtab_at(m);
   int off = -1, hbase = 0;
   if (pk >= 0) {
     const int x = pk & 511, y = (pk >> 9) & 511, z = (pk >> 18) & 255;
@@ -55,17 +78,17 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvArgs a, cons
 #pragma unroll
   for (int i = 0; i < NCO; ++i) acc[i] = 0.f;
 
-  const int K4 = a.CK >> 2;
+  const int K4 = a_CK >> 2;
   for (int ch = 0; ch < nchunks; ++ch) {
     const float *src;
     int Cs, c0, cg0;
-    if (ch < a.nch0) { src = a.src0; Cs = a.C0; c0 = ch * a.CK; cg0 = c0; }
-    else { src = a.src1; Cs = a.C1; c0 = (ch - a.nch0) * a.CK; cg0 = a.C0 + c0; }
+    if (ch < a.nch0) { src = a.src0; Cs = a.C0; c0 = ch * a_CK; cg0 = c0; }
+    else { src = a.src1; Cs = a.C1; c0 = (ch - a.nch0) * a_CK; cg0 = a.C0 + c0; }
     __syncthreads();
-    for (int i = tid; i < 27 * a.CK * NCO; i += 256) W[i] = wsm[(size_t)ch * 27 * a.CK * NCO + i];
+    for (int i = tid; i < 27 * a_CK * NCO; i += 256) W[i] = wsm[(size_t)ch * 27 * a_CK * NCO + i];
     for (int i = tid; i < HV * K4; i += 256) {
       const int hv = i / K4, q = i - hv * K4;
-      const int hp = a.hvtab[hv];
+      const int hp = hvtab_at(hv);
       const int cx = x0 - 1 + (hp & 511), cy = y0 - 1 + ((hp >> 9) & 511), cz = z0 - 1 + ((hp >> 18) & 255);
       f32x4 w = {0.f, 0.f, 0.f, 0.f};
       if (cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs) {
@@ -84,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvArgs a, cons
     for (int t = t0; t < t1; ++t) {
       const int dz = t / 9, rem = t - dz * 9, dy = rem / 3, dx = rem - dy * 3;
       const float *ap = A + hbase + ((dz * HY + dy) * HX + dx) * S;
-      const float *wp = W + (size_t)t * a.CK * NCO;
+      const float *wp = W + (size_t)t * a_CK * NCO;
       for (int q = 0; q < K4; ++q) {
         const f32x4 av = *reinterpret_cast<const f32x4 *>(ap + 4 * q);
 #pragma unroll
@@ -148,6 +171,17 @@ hipError_t launch_conv_smalln(const ConvArgs &a, int MB, const float *wsm, hipSt
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev & 63][v] = true;
+  }
+  if (v == 0 && a.CK == 32 && a.bz == 4 && a.by == 4 && a.bx == 4) {
+    static bool spec_set[64] = {false};
+    if (!spec_set[dev & 63]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_smalln_kernel<4, 4, 4, 4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      spec_set[dev & 63] = true;
+    }
+    hipLaunchKernelGGL((conv_smalln_kernel<4, 4, 4, 4>), grid, dim3(256), lds, st, a, wsm, TM);
+    return hipGetLastError();
   }
   if (v == 0) hipLaunchKernelGGL(conv_smalln_kernel<4>, grid, dim3(256), lds, st, a, wsm, TM);
   else hipLaunchKernelGGL(conv_smalln_kernel<8>, grid, dim3(256), lds, st, a, wsm, TM);
