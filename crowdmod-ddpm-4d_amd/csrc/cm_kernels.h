@@ -122,6 +122,9 @@ hipError_t launch_time_mlp(const float *table, const float *W1, const float *b1,
 // softmax(q k^T / sqrt(d)) v per (sample, head); qkv channels-last [B][S][3E]
 hipError_t launch_attn_core(const float *qkv, float *out, int B, int S, int E, int heads, hipStream_t st);
 
+// Per-step scalars of the sampling loop as a device table, so that one captured graph of a step can be
+// replayed for every step: the step kernels read row tab[*kctr]; step_begin advances the counter.
+struct StepRow { int t; float c_x, c_eps, c_noise, guid; int draw; int step; int pad; };
 struct StepArgs {
   float *x;             // [B,C,H,W,F] reference layout, updated in place
   const float *eps_cl;  // channels-last UNet output [B][L][H][W][cs]
@@ -136,11 +139,18 @@ struct StepArgs {
   long long sample_id_base;
   int step;             // Philox stream index of this step
   int draw;             // 0: z = 0
+  // graph replay: when tab != null the scalars above come from tab[*kctr] and noise / hist are the BASE pointers
+  // of the [nsteps(+1)][Bfull][per] arrays (row k resp. k + 1, sample offset boff within the row)
+  const StepRow *tab; const int *kctr;
+  long long row_stride;  // Bfull * per
+  long long boff;        // b0 * per
 };
 hipError_t launch_sampler_step(const StepArgs &a, hipStream_t st);
 hipError_t launch_q_sample(const float *x0, const long long *t, const float *eps, const float *sab, const float *s1m,
                            float *xt, int B, long long per, hipStream_t st);
 hipError_t launch_fill_t(long long *t, int B, long long value, hipStream_t st);
+// graph replay: ++*kctr, then t[0..B) = tab[*kctr].t  (one workgroup)
+hipError_t launch_step_begin(long long *t, int B, const StepRow *tab, int *kctr, hipStream_t st);
 // mean((a-b)^2) over n elements -> *loss (single workgroup partials + deterministic final sum)
 hipError_t launch_mse_loss(const float *a, const float *b, long long n, float *partial, float *loss, hipStream_t st);
 // Dropout3d keep-mask / (1-p) per (sample, channel) from the device Philox stream

@@ -603,7 +603,14 @@ hipError_t launch_randn(float *x, int B, long long per, unsigned long long seed,
 // Besides x (reference layout) it rewrites the future frames of the channels-last
 // UNet input so the next step needs no re-assembly.
 // --------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs a) {
+__global__ __launch_bounds__(256) void sampler_step_kernel(StepArgs a) {
+  if (a.tab) {
+    const int k = *a.kctr;
+    const StepRow r = a.tab[k];
+    a.c_x = r.c_x; a.c_eps = r.c_eps; a.c_noise = r.c_noise; a.guid = r.guid; a.draw = r.draw; a.step = r.step;
+    if (a.noise) a.noise += (long long)k * a.row_stride + a.boff;
+    if (a.hist) a.hist += (long long)(k + 1) * a.row_stride + a.boff;
+  }
   const long long per = (long long)a.C * a.H * a.W * a.F;
   const long long total = per * a.B;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -710,6 +717,19 @@ hipError_t launch_dropout_mask(float *mask, int B, int C, float p, unsigned long
 __global__ void fill_t_kernel(long long *t, int B, long long v) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < B) t[i] = v;
+}
+
+__global__ __launch_bounds__(256) void step_begin_kernel(long long *t, int B, const StepRow *tab, int *kctr) {
+  __shared__ int ks;
+  if (threadIdx.x == 0) { ks = *kctr + 1; *kctr = ks; }
+  __syncthreads();
+  const long long v = tab[ks].t;
+  for (int i = threadIdx.x; i < B; i += 256) t[i] = v;
+}
+
+hipError_t launch_step_begin(long long *t, int B, const StepRow *tab, int *kctr, hipStream_t st) {
+  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(256), 0, st, t, B, tab, kctr);
+  return hipGetLastError();
 }
 
 hipError_t launch_fill_t(long long *t, int B, long long value, hipStream_t st) {

@@ -178,6 +178,9 @@ struct cm_model {
   float *ks_scratch = nullptr;  // raw partial outputs of K-split convs [S][B][V][Co]
   size_t ks_scratch_floats = 0;
   float *xstate = nullptr;      // sampler state [B,C,H,W,F]
+  cm::StepRow *d_steptab = nullptr;  // per-step scalars of the current loop (graph replay)
+  size_t steptab_cap = 0;
+  int *d_kctr = nullptr;        // device-side step counter read by the table-driven step kernels
   float *stage_past = nullptr, *stage_fut = nullptr, *stage_out = nullptr;  // host-variant staging
   float *stage_noise = nullptr;
   size_t stage_noise_cap = 0;
@@ -1467,7 +1470,6 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
   if (check_ready(m, B)) return 1;
   if (!s || !d_past || !opts || !d_out) return fail("null argument");
   if (s->T > TIME_ROWS) return fail("timesteps %d exceed the %d-row time-embedding table (embeddings.py:7)", s->T, TIME_ROWS);
-  if (opts->use_graph) return fail("use_graph is reserved and must be 0");
   if (opts->sampler == CM_SAMPLER_FM_EULER && (opts->fm_steps < 1 || opts->fm_time_max_pos < 1 || opts->fm_time_max_pos > TIME_ROWS))
     return fail("flow-matching sampler needs fm_steps >= 1 and 1 <= fm_time_max_pos <= %d", TIME_ROWS);
   DevGuard g(m->device);
@@ -1506,29 +1508,81 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
     CM_HIP(hipEventRecord(m->ev_fork, st));
     for (int ln = 1; ln < lanes; ++ln) CM_HIP(hipStreamWaitEvent(sts[ln], m->ev_fork, 0));
   }
+  // per-step scalars (host): the same numbers drive the eager launches and the graph's device table
+  std::vector<cm::StepRow> rows(order.size());
   for (size_t k = 0; k < order.size(); ++k) {
     const int t = order[k];
-    cm::StepArgs a{};
-    a.C = c.in_channels; a.H = c.rows; a.W = c.cols; a.P = c.past_len; a.F = c.future_len;
-    a.seed = opts->seed; a.step = t; a.cs = 8;
+    cm::StepRow &r = rows[k];
+    r.t = t; r.step = t; r.pad = 0;
     if (opts->sampler == CM_SAMPLER_FM_EULER) {
-      a.c_x = 1.0f; a.c_eps = (float)(1.0 / (double)opts->fm_steps); a.c_noise = 0.f;  // xt + delta * u, flow_matching.py:219
-      a.draw = 0; a.guid = 0.f;
-      a.step = (int)k;
+      r.c_x = 1.0f; r.c_eps = (float)(1.0 / (double)opts->fm_steps); r.c_noise = 0.f;  // xt + delta * u, flow_matching.py:219
+      r.draw = 0; r.guid = 0.f;
+      r.step = (int)k;
     } else if (opts->sampler == CM_SAMPLER_DDIM) {
       const float sab_p = s->tab[CM_TAB_SQRT_ALPHA_BAR][t], s1m_p = s->tab[CM_TAB_SQRT_ONE_MINUS_ALPHA_BAR][t];
       const float sig = opts->ddim_sigma;
-      a.c_x = sab_p / sab_t;
-      a.c_eps = sqrtf(1.0f - sab_p * sab_p - sig * sig) - sab_p * s1m_t / sab_t;
-      a.c_noise = sig;
-      a.draw = 1;                                                  // noise on every step (ddpm.py:264)
-      a.guid = opts->guidance == CM_GUIDANCE_SPARSITY ? opts->lambda_guidance * sqrtf(beta_t) : 0.f;  // ddpm.py:270
+      r.c_x = sab_p / sab_t;
+      r.c_eps = sqrtf(1.0f - sab_p * sab_p - sig * sig) - sab_p * s1m_t / sab_t;
+      r.c_noise = sig;
+      r.draw = 1;                                                  // noise on every step (ddpm.py:264)
+      r.guid = opts->guidance == CM_GUIDANCE_SPARSITY ? opts->lambda_guidance * sqrtf(beta_t) : 0.f;  // ddpm.py:270
       beta_t = s->tab[CM_TAB_BETA][t]; sab_t = sab_p; s1m_t = s1m_p;
     } else {
-      ddpm_coeffs(s, t, &a.c_x, &a.c_eps, &a.c_noise);
-      a.draw = t > 0;                                              // ddpm.py:27
-      a.guid = opts->guidance == CM_GUIDANCE_SPARSITY ? opts->lambda_guidance * sqrtf(s->tab[CM_TAB_BETA][t]) : 0.f;
+      ddpm_coeffs(s, t, &r.c_x, &r.c_eps, &r.c_noise);
+      r.draw = t > 0;                                              // ddpm.py:27
+      r.guid = opts->guidance == CM_GUIDANCE_SPARSITY ? opts->lambda_guidance * sqrtf(s->tab[CM_TAB_BETA][t]) : 0.f;
     }
+  }
+  auto base_args = [&]() {
+    cm::StepArgs a{};
+    a.C = c.in_channels; a.H = c.rows; a.W = c.cols; a.P = c.past_len; a.F = c.future_len;
+    a.seed = opts->seed; a.cs = 8;
+    return a;
+  };
+  const bool graph = opts->use_graph && !m->profile && lanes == 1 && order.size() >= 3;
+  if (graph) {
+    // hipGraph replay: one captured step (the kernels read their per-step scalars from a device table indexed by a
+    // device counter), launched once per remaining step.  Step 0 runs eagerly: it performs the lazy tile set-up
+    // and per-kernel attribute calls that may not happen inside a capture.
+    if (m->steptab_cap < rows.size()) {
+      if (dev_alloc(m, (void **)&m->d_steptab, rows.size() * sizeof(cm::StepRow))) return 1;
+      m->steptab_cap = rows.size();
+    }
+    if (!m->d_kctr && dev_alloc(m, (void **)&m->d_kctr, sizeof(int))) return 1;
+    CM_HIP(hipMemcpyAsync(m->d_steptab, rows.data(), rows.size() * sizeof(cm::StepRow), hipMemcpyHostToDevice, st));
+    CM_HIP(hipMemsetAsync(m->d_kctr, 0xFF, sizeof(int), st));   // -1
+    CM_HIP(hipStreamSynchronize(st));                            // `rows` is host memory of this call
+    auto enqueue_step = [&]() -> int {
+      CM_HIP(cm::launch_step_begin(m->tbuf, B, m->d_steptab, m->d_kctr, st));
+      if (run_ops(m, B, st, 0, 0)) return 1;
+      cm::StepArgs al = base_args();
+      al.B = B; al.x = m->xstate; al.eps_cl = m->eps_cl; al.x8 = m->x8;
+      al.sample_id_base = opts->sample_id_base;
+      al.tab = m->d_steptab; al.kctr = m->d_kctr; al.row_stride = (long long)B * per; al.boff = 0;
+      al.hist = d_history; al.noise = d_noise;
+      CM_HIP(cm::launch_sampler_step(al, st));
+      return 0;
+    };
+    if (enqueue_step()) return 1;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    CM_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+    const int rc_cap = enqueue_step();
+    hipError_t ec = hipStreamEndCapture(st, &g);
+    if (rc_cap || ec != hipSuccess) { if (g) hipGraphDestroy(g); return rc_cap ? 1 : fail("graph capture failed: %s", hipGetErrorString(ec)); }
+    ec = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (ec != hipSuccess) { hipGraphDestroy(g); return fail("graph instantiate failed: %s", hipGetErrorString(ec)); }
+    for (size_t k = 1; k < order.size() && ec == hipSuccess; ++k) ec = hipGraphLaunch(ge, st);
+    if (ec == hipSuccess) ec = hipStreamSynchronize(st);
+    hipGraphExecDestroy(ge);
+    hipGraphDestroy(g);
+    if (ec != hipSuccess) return fail("graph replay failed: %s", hipGetErrorString(ec));
+  }
+  for (size_t k = 0; !graph && k < order.size(); ++k) {
+    const int t = order[k];
+    cm::StepArgs a = base_args();
+    const cm::StepRow &r = rows[k];
+    a.step = r.step; a.c_x = r.c_x; a.c_eps = r.c_eps; a.c_noise = r.c_noise; a.draw = r.draw; a.guid = r.guid;
     for (int ln = 0; ln < lanes; ++ln) {
       const int b0 = off[ln], Bn = Bl[ln];
       hipStream_t ls = sts[ln];

@@ -13,6 +13,7 @@ sharded over GPUs.  `x_T=` / `noise=` inject explicit tensors (parity tests).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -98,7 +99,7 @@ class DDPM_model:
         o.first_steps = int(first_steps)
         o.seed = int(self.seed if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         o.sample_id_base = int(sample_id_base)
-        o.use_graph = 0
+        o.use_graph = 1 if os.environ.get("CM_USE_GRAPH") else 0   # hipGraph replay of the step (opt-in)
         return o
 
     def _run_loop(self, past, sampler_obj: DDPM, nsamples: int, opts: native.cm_sample_opts, history: bool,

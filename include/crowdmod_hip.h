@@ -149,8 +149,8 @@ typedef struct cm_sample_opts {
   int32_t first_steps;    /* >0: run only the first n visited steps (benchmarks) */
   uint64_t seed;          /* device RNG seed (used when x_T / noise are NULL)    */
   int64_t sample_id_base; /* global index of sample 0 (batch sharding)           */
-  int32_t use_graph;      /* reserved, must be 0: hipGraph replay of the per-step launch sequence is not built
-                             (the loop is kernel-latency-bound, not launch-bound, even at B = 2: DESIGN.md)   */
+  int32_t use_graph;      /* 1: capture one step as a hipGraph (per-step scalars in a device table) and replay
+                             it for the remaining steps; the call then returns after the loop has finished   */
   int32_t reserved;
   /* CM_SAMPLER_FM_EULER -- FM_model.sampling_with_euler (models/flow_matching/flow_matching.py:203-224):
    * x <- x + (1/N) u(x, idx_i, past) for t_i = linspace(0,1,N)[i], idx_i = clamp(t_i * TIME_MAX_POS, 0,

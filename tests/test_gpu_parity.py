@@ -545,10 +545,6 @@ def test_abi_rejects_bad_arguments_loudly():
         native.check(L.cm_unet_forward(h, None, d.ptr, d.ptr, d.ptr, 2, None))
     s = DDPM(timesteps=50, scale=0.5)
     o = native.cm_sample_opts()
-    o.use_graph = 1
-    with pytest.raises(native.NativeError, match="use_graph"):
-        native.check(L.cm_sample_loop(h, s._handle, d.ptr, None, None, C.byref(o), d.ptr, None, 2, None))
-    o = native.cm_sample_opts()
     o.sampler = native.SAMPLER_FM_EULER
     o.fm_steps, o.fm_time_max_pos = 4, 2000
     with pytest.raises(native.NativeError, match="flow-matching"):
@@ -557,3 +553,37 @@ def test_abi_rejects_bad_arguments_loudly():
         native.check(L.cm_train_apply(h, None))
     with pytest.raises(ValueError):
         net(fut[:, :2], np.array([1, 2]), past)                   # channel mismatch is caught before the call
+
+
+@pytest.mark.gpu
+def test_graph_replay_is_bit_identical_to_eager_launches(monkeypatch):
+    """use_graph = 1: one captured step replayed through a hipGraph (per-step scalars in a device table) must give
+    exactly the eager loop's result -- DDPM with injected noise + history, DDIM, device-drawn noise."""
+    from crowdmod_ddpm_4d_amd.config import AttrDict
+    from crowdmod_ddpm_4d_amd.ddpm_model import DDPM_model
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    C_, B, T = 3, 2, 20
+    cfg = AttrDict({
+        "MACROPROPS": {"ROWS": NARROW["H"], "COLS": NARROW["W"]},
+        "DATASET": {"PAST_LEN": NARROW["P"], "FUTURE_LEN": NARROW["F"], "BATCH_SIZE": B},
+        "MODEL": {"DDPM": {"TIMESTEPS": T, "SCALE": 0.5, "SIGMA": 0.0, "GUIDANCE": "Sparsity", "LAMBDA_GUIDANCE": 0.05, "UNET": {
+            "CONDITION": "Past", "NUM_RES_BLOCKS": 1, "BASE_CH": 8, "BASE_CH_MULT": [1, 2, 4],
+            "APPLY_ATTENTION": [False, False, True, False], "DROPOUT_RATE": 0.1, "TIME_EMB_MULT": 4}}}})
+    past, fut = synth_inputs(B, C_, NARROW["H"], NARROW["W"], NARROW["P"], NARROW["F"], "graph")
+    x_T = prng.normal(7, "graph/xT", fut.size).reshape(fut.shape)
+    noise = prng.normal(7, "graph/z", T * fut.size).reshape((T,) + fut.shape)
+    out = {}
+    for mode in ("eager", "graph"):
+        if mode == "graph":
+            monkeypatch.setenv("CM_USE_GRAPH", "1")
+        else:
+            monkeypatch.delenv("CM_USE_GRAPH", raising=False)
+        m = DDPM_model(cfg, "DDPM-UNet", C_)
+        m.denoiser.load_state_dict(spec.init_params(narrow_cfg(C_), SEED_W))
+        s = DDPM(timesteps=T, scale=0.5)
+        x, hist = m._generate_ddpm(past, s, B, history=True, x_T=x_T, noise=noise)
+        xd, _ = m._generate_ddim(past, np.arange(0, T - 1, 3), s, B, x_T=x_T, noise=noise[:7])
+        xr, _ = m._generate_ddpm(past, s, B)          # device Philox noise
+        out[mode] = (x, np.stack(hist), xd, xr)
+    for a, b in zip(out["eager"], out["graph"]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
