@@ -64,7 +64,12 @@ __global__ __launch_bounds__(256, (BZ != 0 && MB * NB <= 4 ? CM_SPEC_OCC : 2)) v
   unsigned long long tst[6] = {0, 0, 0, 0, 0, 0};
 #define CM_RT(i) if (a.dbg & 8) tst[i] = __builtin_amdgcn_s_memrealtime();
   CM_RT(0)
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+  // consecutive block ids -- spatial neighbours that share halo voxels -- would land on 8 different L2s.
+  // Block id i therefore takes logical tile (i % 8) * (n / 8) + i / 8: every XCD works through a contiguous
+  // range of tiles (whole samples), and a neighbour's halo is an L2 hit instead of a fabric / HBM access.
   int tile = blockIdx.x;
+  if (!(gridDim.x & 7) && !(a.dbg & 4096)) tile = (tile & 7) * (int)(gridDim.x >> 3) + (tile >> 3);
   const int tx = tile % a.ntx; tile /= a.ntx;
   const int ty = tile % a.nty; tile /= a.nty;
   const int tz = tile % a.ntz;
