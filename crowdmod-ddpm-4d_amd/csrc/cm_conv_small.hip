@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvArgs a, cons
   const int a_bz = SPEC ? BZ : a.bz, a_by = SPEC ? BY : a.by, a_bx = SPEC ? BX : a.bx, a_CK = SPEC ? 32 : a.CK;
   const int tid = threadIdx.x;
   int tile = blockIdx.x;
+  if (!(gridDim.x & 7)) tile = (tile & 7) * (int)(gridDim.x >> 3) + (tile >> 3);  // XCD-aware order (see cm_conv.hip)
   const int tx = tile % a.ntx; tile /= a.ntx;
   const int ty = tile % a.nty; tile /= a.nty;
   const int tz = tile % a.ntz;
