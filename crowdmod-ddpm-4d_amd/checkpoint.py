@@ -48,7 +48,22 @@ class _LazyStorage:
 def _rebuild_tensor_v2(storage, storage_offset, size, stride, requires_grad=False, backward_hooks=None,
                        metadata=None):
     flat = storage.array()
-    size, stride = tuple(size), tuple(stride)
+    size, stride = tuple(int(v) for v in size), tuple(int(v) for v in stride)
+    storage_offset = int(storage_offset)
+    # Bounds of the strided view, as torch's weights_only loader enforces them: a crafted file must not
+    # make as_strided read outside the storage bytes of its zip entry.
+    if len(size) != len(stride) or storage_offset < 0 or any(v < 0 for v in size) or any(v < 0 for v in stride):
+        raise pickle.UnpicklingError(f"invalid tensor geometry: offset {storage_offset}, size {size}, stride {stride}")
+    numel = 1
+    for v in size:
+        numel *= v
+    if numel > 0:
+        last = storage_offset + sum((n - 1) * st for n, st in zip(size, stride))
+        if last >= flat.size:
+            raise pickle.UnpicklingError(f"tensor view (offset {storage_offset}, size {size}, stride {stride}) "
+                                         f"reaches element {last} of a storage of {flat.size}")
+    else:
+        return np.zeros(size, dtype=flat.dtype)
     if len(size) == 0:
         return np.array(flat[storage_offset], dtype=flat.dtype)
     itemsize = flat.dtype.itemsize

@@ -1,0 +1,218 @@
+// Host-side self-test of libcrowdmod_hip's C++ (`make asan`): the plan builder, the weight / index
+// packers, the tile planner with its coordinate tables, the schedule and the error paths, compiled
+// under AddressSanitizer + UBSan and run WITHOUT a GPU ("sanitizers": GPU ASan is
+// not available on this pool, so the pointer-heavy host code is what gets sanitised).  It includes
+// cm_model.cpp itself to reach the internal functions; no kernel is ever launched.
+#include "cm_model.cpp"
+
+#include <cstdlib>
+#include <random>
+
+namespace {
+
+int g_checks = 0;
+#define EXPECT(cond)                                                                  \
+  do {                                                                                \
+    ++g_checks;                                                                       \
+    if (!(cond)) { fprintf(stderr, "selftest FAILED: %s (%s:%d)\n", #cond, __FILE__, __LINE__); exit(1); } \
+  } while (0)
+
+void test_schedule() {
+  for (int T : {2, 3, 50, 1000}) {
+    cm_schedule *s = nullptr;
+    EXPECT(cm_schedule_create(T, 0.5f, 1e-4f, 2e-2f, -1, &s) == 0);
+    std::vector<float> buf((size_t)T);
+    for (int w = 0; w < 6; ++w) EXPECT(cm_schedule_table(s, w, buf.data(), T) == 0);
+    EXPECT(cm_schedule_table(s, 6, buf.data(), T) != 0);
+    EXPECT(cm_schedule_table(s, 0, buf.data(), T - 1) != 0);
+    cm_sample_opts o{};
+    int32_t n = 0;
+    o.sampler = CM_SAMPLER_DDPM;
+    EXPECT(cm_sample_num_steps(s, &o, &n) == 0 && n == T);
+    for (int d : {1, 2, 7, 100, 5000}) {
+      o.sampler = CM_SAMPLER_DDIM; o.ddim_divider = d;
+      EXPECT(cm_sample_num_steps(s, &o, &n) == 0 && n == (T - 1 + d - 1) / d);
+    }
+    o.sampler = CM_SAMPLER_FM_EULER; o.fm_steps = 10; o.fm_time_max_pos = 1000;
+    EXPECT(cm_sample_num_steps(s, &o, &n) == 0 && n == 10);
+    o.first_steps = 3;
+    EXPECT(cm_sample_num_steps(s, &o, &n) == 0 && n == 3);
+    // a host-only schedule must refuse device work instead of dereferencing null tables
+    EXPECT(cm_q_sample(s, buf.data(), (const int64_t *)buf.data(), buf.data(), buf.data(), 1, 1, nullptr) != 0);
+    EXPECT(cm_schedule_destroy(s) == 0);
+  }
+  cm_schedule *s = nullptr;
+  EXPECT(cm_schedule_create(1, 0.5f, 1e-4f, 2e-2f, -1, &s) != 0);
+  EXPECT(cm_schedule_create(10, 0.5f, 1e-4f, 2e-2f, -1, nullptr) != 0);
+}
+
+cm_unet_config atc_cfg(int C, int rows, int cols, int device) {
+  cm_unet_config c{};
+  c.in_channels = c.out_channels = C;
+  c.num_res_blocks = 1; c.base_channels = 32; c.n_levels = 3;
+  const int mult[3] = {1, 2, 4}, att[3] = {0, 0, 1};
+  for (int i = 0; i < 3; ++i) { c.channel_mult[i] = mult[i]; c.apply_attention[i] = att[i]; }
+  c.time_multiple = 4; c.rows = rows; c.cols = cols; c.past_len = 5; c.future_len = 3; c.max_batch = 2; c.device = device;
+  return c;
+}
+
+void test_plan_and_params() {
+  std::mt19937 rng(1);
+  std::uniform_real_distribution<float> U(-1.f, 1.f);
+  for (int C : {3, 4}) {
+    cm_unet_config c = atc_cfg(C, 12, 36, -1);
+    cm_model *m = nullptr;
+    EXPECT(cm_model_create(&c, &m) == 0);
+    int32_t n = 0;
+    EXPECT(cm_model_num_params(m, &n) == 0 && n == 169);
+    for (int i = 0; i < n; ++i) {
+      const char *name = nullptr; int64_t shape[5]; int32_t nd = 0;
+      EXPECT(cm_model_param_info(m, i, &name, shape, &nd) == 0 && name && nd >= 1 && nd <= 5);
+      int64_t numel = 1;
+      for (int d = 0; d < nd; ++d) numel *= shape[d];
+      std::vector<float> w((size_t)numel), back((size_t)numel);
+      for (auto &v : w) v = U(rng);
+      EXPECT(cm_model_set_param(m, name, w.data(), numel) == 0);
+      EXPECT(cm_model_set_param(m, name, w.data(), numel + 1) != 0);
+      EXPECT(cm_model_get_param(m, name, back.data(), numel) == 0 && back == w);
+    }
+    EXPECT(cm_model_param_info(m, n, nullptr, nullptr, nullptr) != 0);
+    EXPECT(cm_model_set_param(m, "no.such.tensor", (const float *)&n, 1) != 0);
+    EXPECT(cm_model_finalize(m) != 0);                     // host-only: no CPU path
+    EXPECT(std::string(cm_last_error()).find("host-only") != std::string::npos);
+    EXPECT(cm_unet_forward(m, nullptr, nullptr, nullptr, nullptr, 1, nullptr) != 0);
+    EXPECT(cm_model_destroy(m) == 0);
+  }
+  cm_unet_config bad = atc_cfg(3, 12, 36, -1);
+  cm_model *m = nullptr;
+  bad.base_channels = 12; EXPECT(cm_model_create(&bad, &m) != 0);
+  bad = atc_cfg(3, 12, 36, -1); bad.n_levels = 9; EXPECT(cm_model_create(&bad, &m) != 0);
+  bad = atc_cfg(9, 12, 36, -1); EXPECT(cm_model_create(&bad, &m) != 0);
+  bad = atc_cfg(3, 12, 36, -1); bad.max_batch = 0; EXPECT(cm_model_create(&bad, &m) != 0);
+  EXPECT(cm_model_create(nullptr, &m) != 0);
+}
+
+void test_packers() {
+  std::mt19937 rng(2);
+  std::uniform_real_distribution<float> U(-1.f, 1.f);
+  struct Case { int Co, Ci, ntaps, Ci_pad, CK, NB; };
+  const Case cases[] = {{32, 32, 27, 32, 32, 1}, {64, 96, 27, 96, 32, 2}, {32, 3, 27, 8, 8, 1}, {4, 32, 27, 32, 32, 1},
+                        {384, 128, 1, 128, 128, 2}, {128, 192, 1, 192, 64, 2}, {40, 24, 27, 24, 8, 2}};
+  for (const Case &c : cases) {
+    std::vector<float> W((size_t)c.Co * c.Ci * c.ntaps);
+    for (auto &v : W) v = U(rng);
+    const std::vector<float> wi = to_internal_taps(W.data(), c.Co, c.Ci, c.ntaps);
+    EXPECT(wi.size() == W.size());
+    const std::vector<float> wf = pack_conv_weights(wi.data(), c.Co, c.Ci, c.ntaps, c.Ci_pad, c.CK, c.NB);
+    const int TN = 32 * c.NB, ntn = (c.Co + TN - 1) / TN;
+    EXPECT(wf.size() == (size_t)ntn * (c.Ci_pad / c.CK) * c.ntaps * (c.CK / 8) * c.NB * 256);
+    // every reference weight appears exactly once; everything else is zero padding
+    double sa = 0, sb = 0;
+    for (float v : wi) sa += std::fabs(v);
+    for (float v : wf) sb += std::fabs(v);
+    EXPECT(std::fabs(sa - sb) <= 1e-6 * sa + 1e-9);
+    if (c.ntaps == 27) {
+      const std::vector<float> wp = parity_weights(wi, c.Co, c.Ci);
+      EXPECT(wp.size() == (size_t)8 * c.Co * c.Ci * 8);
+      // each parity class redistributes all 27 taps: the tap sum per (co, ci) is preserved
+      for (int p = 0; p < 8; ++p) {
+        double s27 = 0, s8 = 0;
+        for (int t = 0; t < 27; ++t) s27 += wi[t];
+        for (int e = 0; e < 8; ++e) s8 += wp[(size_t)p * c.Co * c.Ci * 8 + e];
+        EXPECT(std::fabs(s27 - s8) < 1e-5);
+      }
+    }
+    // index version (training re-pack): same positions are filled
+    std::vector<int> src((size_t)c.Co * c.Ci * c.ntaps);
+    for (size_t i = 0; i < src.size(); ++i) src[i] = (int)i;
+    const std::vector<int> pi = pack_conv_indices(src, 1, c.Co, c.Ci, c.ntaps, c.Ci_pad, c.CK, c.NB);
+    EXPECT(pi.size() == wf.size());
+    for (size_t i = 0; i < pi.size(); ++i) {
+      EXPECT(pi[i] >= -1 && pi[i] < (int)src.size());
+      if (pi[i] >= 0) EXPECT(wf[i] == wi[(size_t)pi[i]]); else EXPECT(wf[i] == 0.f);
+    }
+  }
+}
+
+void check_tables(const cm::ConvArgs &a, int MB) {
+  const int HZ = (a.bz - 1) * a.stride + a.td, HY = (a.by - 1) * a.stride + a.td, HX = (a.bx - 1) * a.stride + a.td;
+  const int hv = cm::conv_halo_voxels(a);
+  EXPECT(hv == a.bs * HZ * HY * HX);
+  std::vector<int> hvt((size_t)hv), mt((size_t)32 * MB);
+  cm::conv_build_tables(a, MB, hvt.data(), mt.data());
+  for (int v : hvt) {
+    EXPECT((v & 511) < HX && ((v >> 9) & 511) < HY && ((v >> 18) & 255) < HZ && (v >> 26) < a.bs);
+  }
+  int valid = 0;
+  for (int v : mt) {
+    if (v < 0) continue;
+    ++valid;
+    EXPECT((v & 511) < a.bx && ((v >> 9) & 511) < a.by && ((v >> 18) & 255) < a.bz && (v >> 26) < a.bs);
+  }
+  EXPECT(valid == a.bs * a.bz * a.by * a.bx && valid <= 32 * MB);
+  EXPECT(cm::conv_lds_bytes(a, MB, 1) > 0);
+}
+
+void test_tile_planner() {
+  // every 3x3x3 / 1x1x1 layer shape of the three reference grids, through the same chooser the model uses
+  struct Grid { int Z, Y, X; };
+  const Grid grids[] = {{8, 12, 36}, {8, 28, 24}, {8, 24, 72}, {8, 4, 8}};
+  for (const Grid &g : grids)
+    for (int level = 0; level < 3; ++level)
+      for (int ci : {32, 64, 128, 192, 256})
+        for (int co : {32, 64, 128})
+          for (int mode = 0; mode < 4; ++mode) {   // 0: 3x3x3 s1, 1: stride 2, 2: parity upsample, 3: 1x1x1
+            Op op;
+            op.kind = OP_CONV;
+            cm::ConvArgs &a = op.ca;
+            const int Z = g.Z >> level, Y = g.Y >> level, X = g.X >> level;
+            if (Z < 1 || Y < 1 || X < 1) continue;
+            if (mode == 1 && (Z < 2 || Y < 2 || X < 2)) continue;
+            a.C0 = ci; a.C1 = 0; a.Co = co; a.CK = mode == 3 ? 64 : 32;
+            if (ci % a.CK) continue;
+            a.ntaps = mode == 3 ? 1 : (mode == 2 ? 8 : 27);
+            a.td = mode == 3 ? 1 : (mode == 2 ? 2 : 3);
+            a.stride = mode == 1 ? 2 : 1; a.par = mode == 2; a.ups = 0;
+            a.Zs = Z; a.Ys = Y; a.Xs = X;
+            const int os = mode == 2 ? 2 : 1;
+            a.Zo = mode == 1 ? Z / 2 : Z * os; a.Yo = mode == 1 ? Y / 2 : Y * os; a.Xo = mode == 1 ? X / 2 : X * os;
+            op.NB = co > 32 ? 2 : 1;
+            static Act dummy;
+            op.stat_act = &dummy;
+            pick_tile(op, TUNE_BATCH);
+            EXPECT(op.MB >= 1 && op.MB <= 8 && cm::conv_variant_exists(op.MB, op.NB));
+            EXPECT(a.bs >= 1 && a.bz >= 1 && a.by >= 1 && a.bx >= 1);
+            EXPECT(a.bs * a.bz * a.by * a.bx <= 32 * op.MB);
+            EXPECT(a.ntz * a.bz >= a.Zo / os && a.nty * a.by >= a.Yo / os && a.ntx * a.bx >= a.Xo / os);
+            EXPECT(cm::conv_lds_bytes(a, op.MB, op.NB) <= 160 * 1024);
+            check_tables(a, op.MB);
+          }
+}
+
+void test_misc_errors() {
+  EXPECT(cm_abi_version() == CM_ABI_VERSION);
+  EXPECT(cm_device_count(nullptr) != 0);
+  EXPECT(cm_model_destroy(nullptr) == 0);
+  EXPECT(cm_schedule_destroy(nullptr) == 0);
+  EXPECT(cm_train_set_lr(nullptr, 1.f) != 0);
+  EXPECT(cm_train_set_sample_base(nullptr, 0) != 0);
+  int32_t n = 0;
+  EXPECT(cm_model_num_params(nullptr, &n) != 0);
+  EXPECT(cm_profile_enable(nullptr, 1) != 0);
+  EXPECT(cm_frame_metrics(0, nullptr, nullptr, 1, 1, 1, 1, 1, nullptr, nullptr) != 0);
+  EXPECT(std::string(cm_last_error()).size() > 0);
+  // linspace restatement: endpoints and symmetry
+  EXPECT(linspace_f32(0.f, 1.f, 10, 0) == 0.f && linspace_f32(0.f, 1.f, 10, 9) == 1.f && linspace_f32(3.f, 5.f, 1, 0) == 3.f);
+}
+
+}  // namespace
+
+int main() {
+  test_schedule();
+  test_plan_and_params();
+  test_packers();
+  test_tile_planner();
+  test_misc_errors();
+  printf("selftest ok: %d checks\n", g_checks);
+  return 0;
+}

@@ -80,13 +80,6 @@ bool conv_variant_exists(int MB, int NB);
 bool conv_smalln_ok(const ConvArgs &a, int MB);
 size_t conv_smalln_lds(const ConvArgs &a, int MB);
 hipError_t launch_conv_smalln(const ConvArgs &a, int MB, const float *wsm, hipStream_t st);
-// Persistent, software-pipelined 3x3x3 kernel (cm_conv2.hip): MB x NB accumulator blocks
-// per wave (K split over the 4 waves), grid_x persistent workgroups pulling tiles from
-// ctr (zeroed int[2 * number of N tiles]).
-size_t conv2_lds_bytes(const ConvArgs &a, int MB, int NB);
-int conv2_nv(const ConvArgs &a);
-bool conv2_variant_exists(int MB, int NB, int NV);
-hipError_t launch_conv2(const ConvArgs &a, int MB, int NB, int grid_x, int *ctr, hipStream_t st);
 
 // ---- small kernels --------------------------------------------------------
 // Per-(sample, slice, channel) mean and M2 of a channels-last tensor.
@@ -149,6 +142,8 @@ hipError_t launch_sampler_step(const StepArgs &a, hipStream_t st);
 hipError_t launch_q_sample(const float *x0, const long long *t, const float *eps, const float *sab, const float *s1m,
                            float *xt, int B, long long per, hipStream_t st);
 hipError_t launch_fill_t(long long *t, int B, long long value, hipStream_t st);
+// *count = number of NaN / Inf elements of x[0..n)  (one workgroup, no atomics)
+hipError_t launch_count_nonfinite(const float *x, long long n, int *count, hipStream_t st);
 // graph replay: ++*kctr, then t[0..B) = tab[*kctr].t  (one workgroup)
 hipError_t launch_step_begin(long long *t, int B, const StepRow *tab, int *kctr, hipStream_t st);
 // mean((a-b)^2) over n elements -> *loss (single workgroup partials + deterministic final sum)

@@ -732,6 +732,26 @@ hipError_t launch_step_begin(long long *t, int B, const StepRow *tab, int *kctr,
   return hipGetLastError();
 }
 
+// Sampler-output health check (failure detection): one workgroup counts the
+// elements whose exponent field is all ones.
+__global__ __launch_bounds__(1024) void count_nonfinite_kernel(const float *__restrict__ x, long long n, int *__restrict__ count) {
+  __shared__ int sh[1024];
+  int c = 0;
+  for (long long i = threadIdx.x; i < n; i += 1024) c += ((__float_as_uint(x[i]) & 0x7f800000u) == 0x7f800000u) ? 1 : 0;
+  sh[threadIdx.x] = c;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = sh[0];
+}
+
+hipError_t launch_count_nonfinite(const float *x, long long n, int *count, hipStream_t st) {
+  hipLaunchKernelGGL(count_nonfinite_kernel, dim3(1), dim3(1024), 0, st, x, n, count);
+  return hipGetLastError();
+}
+
 hipError_t launch_fill_t(long long *t, int B, long long value, hipStream_t st) {
   hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, st, t, B, value);
   return hipGetLastError();

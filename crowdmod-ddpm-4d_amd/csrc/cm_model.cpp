@@ -108,9 +108,6 @@ struct Op {
   int small_nco = 4;
   float *d_zero_bias = nullptr;
   const Act *out_act = nullptr, *resid_act = nullptr;
-  bool v2 = false;      // persistent pipelined kernel (cm_conv2.hip)
-  int NW = 4, grid_x = 0;
-  int *d_ctr = nullptr; // its tile counters
   double flops_per_sample = 0;
   std::string label;
   double prof_ms = 0;
@@ -181,6 +178,7 @@ struct cm_model {
   cm::StepRow *d_steptab = nullptr;  // per-step scalars of the current loop (graph replay)
   size_t steptab_cap = 0;
   int *d_kctr = nullptr;        // device-side step counter read by the table-driven step kernels
+  int *d_nonfinite = nullptr;   // result word of the sampler-output health check
   float *stage_past = nullptr, *stage_fut = nullptr, *stage_out = nullptr;  // host-variant staging
   float *stage_noise = nullptr;
   size_t stage_noise_cap = 0;
@@ -480,52 +478,6 @@ void pick_tile(Op &op, int B) {
   op.tuned_B = B;
 }
 
-// Tile geometry for the persistent kernel (cm_conv2.hip): one sample per tile, MB row
-// blocks, halo image small enough for 2-3 workgroups per CU.
-void pick_tile2(Op &op, int B) {
-  cm::ConvArgs &a = op.ca;
-  const int NB = op.NB;
-  const int Zo = a.Zo, Yo = a.Yo, Xo = a.Xo;
-  const int vox = Zo * Yo * Xo;
-  const int ntn = (a.Co + 32 * NB - 1) / (32 * NB);
-  double best = -1;
-  int bbz = 1, bby = 1, bbx = 1, bMB = 0;
-  a.bs = 1;
-  for (int bz = 1; bz <= Zo; ++bz)
-    for (int by = 1; by <= Yo; ++by)
-      for (int bx = 1; bx <= Xo; ++bx) {
-        const int nbox = bz * by * bx;
-        const int MB = (nbox + 31) / 32;
-        if (MB > 4) continue;
-        a.bz = bz; a.by = by; a.bx = bx;
-        const int NV = cm::conv2_nv(a);
-        if (!NV || !cm::conv2_variant_exists(MB, NB, NV)) continue;
-        const size_t lds = cm::conv2_lds_bytes(a, MB, NB);
-        if (lds > 80 * 1024) continue;
-        const long ntz = (Zo + bz - 1) / bz, nty = (Yo + by - 1) / by, ntx = (Xo + bx - 1) / bx;
-        const double tiles = (double)ntz * nty * ntx * B * ntn;
-        const double util = (double)vox * B * ntn / (tiles * 32.0 * MB);
-        const int occ = std::max(1, std::min((int)(160 * 1024 / lds), 2));
-        const double per_cu = tiles / 256.0;
-        const double balance = (tiles <= 256.0 * occ) ? per_cu / std::ceil(per_cu - 1e-9) : per_cu / (per_cu + 0.5);
-        const double hv = (double)(bz + 2) * (by + 2) * (bx + 2);
-        const double halo = 1.0 / (1.0 + 0.02 * hv / (32.0 * MB));
-        const double amort = 1.0 - 0.08 / (MB * NB);
-        const double occf = occ >= 2 ? 1.0 : 0.85;
-        const double score = util * balance * halo * amort * occf;
-        if (score > best) { best = score; bbz = bz; bby = by; bbx = bx; bMB = MB; }
-      }
-  a.bz = bbz; a.by = bby; a.bx = bbx;
-  op.MB = bMB;
-  a.ntz = (Zo + bbz - 1) / bbz; a.nty = (Yo + bby - 1) / bby; a.ntx = (Xo + bbx - 1) / bbx;
-  const size_t lds = cm::conv2_lds_bytes(a, bMB, NB);
-  const int occ = std::max(1, std::min((int)(160 * 1024 / lds), 2));
-  const long tiles = (long)a.ntz * a.nty * a.ntx * B;
-  (void)tiles;
-  op.grid_x = 256 * occ;
-  op.tuned_B = B;
-}
-
 struct ConvSpec {
   const Act *s0;
   const Act *s1 = nullptr;
@@ -571,9 +523,6 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   }
   if (!a.CK) return fail("conv %s: channel counts %d/%d not multiples of 8", s.wname.c_str(), a.C0, a.C1);
   a.nch0 = a.C0 / a.CK; a.nch1 = a.C1 / a.CK;
-  // large-spatial 3x3x3 layers run on the persistent M-split kernel (all output
-  // channels per workgroup, up to 128); the K-split kernel keeps the rest
-  op.v2 = (s.ntaps == 27 && !parity && a.CK == 32 && s.stride == 1 && s.out->V() >= 128 && getenv("CM_CONV2"));  // experimental
   op.NB = s.Co > 32 ? 2 : 1;
   // tiny-spatial layers are overhead-bound, not throughput-bound: fewer, fatter workgroups
   // (all 128 output channels per workgroup, K split over workgroups) amortise the per-workgroup
@@ -587,10 +536,6 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     // tuner policies (tools/tune_tiles.py): N blocking of the 64- / 128-channel 3x3x3 layers
     if (s.Co == 64 && getenv("CM_NB64")) op.NB = atoi(getenv("CM_NB64"));
     if (s.Co == 128 && getenv("CM_NB128")) op.NB = atoi(getenv("CM_NB128"));
-  }
-  if (op.v2) {
-    if (dev_alloc(m, (void **)&op.d_ctr, 64 * sizeof(int))) return 1;
-    CM_HIP(hipMemset(op.d_ctr, 0, 64 * sizeof(int)));
   }
   const Param &w = P(m, s.wname);
   const Param &b = P(m, s.bname);
@@ -612,7 +557,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     wf = pack_conv_weights(wi.data(), (int)w.shape[0], Ci_ref, s.ntaps, Ci_pad, a.CK, op.NB);
   }
   // the UNet's last conv (base -> C channels): vector-ALU kernel instead of a 32-wide MFMA tile
-  if (s.ntaps == 27 && s.stride == 1 && !s.ups && s.Co <= 8 && !s.stats && !s.temb && !s.resid && !op.v2 &&
+  if (s.ntaps == 27 && s.stride == 1 && !s.ups && s.Co <= 8 && !s.stats && !s.temb && !s.resid &&
       !getenv("CM_NO_SMALLN")) {
     op.small_n = true;
     op.small_nco = s.Co <= 4 ? 4 : 8;
@@ -659,7 +604,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     if (upload(m, zb, &op.d_zero_bias)) return 1;
   }
   // fuse the 1x1x1 skip conv when this conv runs on the 27-tap register-ring path without K split
-  if (s.skip0 && s.ntaps == 27 && !parity && a.CK == 32 && !op.v2 && !op.small_n && s.stride == 1 &&
+  if (s.skip0 && s.ntaps == 27 && !parity && a.CK == 32 && !op.small_n && s.stride == 1 &&
       s.skip0->C % 32 == 0 && (!s.skip1 || s.skip1->C % 32 == 0) && !getenv("CM_NO_FUSE_SKIP")) {
     const Param &w2 = P(m, s.skip_w);
     const Param &b2 = P(m, s.skip_b);
@@ -901,8 +846,7 @@ int build_time_table(cm_model *m) {
 int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   if (op.skip_if_fused && !m->train_fwd) return 0;  // absorbed by the block's conv_2 (inference plan)
   if (op.tuned_B < 0) {
-    if (op.v2) pick_tile2(op, TUNE_BATCH);
-    else pick_tile(op, TUNE_BATCH);
+    pick_tile(op, TUNE_BATCH);
     op.tuned_B = B;
     std::vector<int> hv((size_t)cm::conv_halo_voxels(op.ca)), mt((size_t)32 * op.MB);
     cm::conv_build_tables(op.ca, op.MB, hv.data(), mt.data());
@@ -974,10 +918,6 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     CM_HIP(cm::launch_ksplit_combine(cb, st));
   } else if (op.small_n) {
     CM_HIP(cm::launch_conv_smalln(ca, op.MB, op.d_wsmall, st));
-  } else if (op.v2) {
-    const long tiles = (long)ca.ntz * ca.nty * ca.ntx * B;
-    const int gx = (int)std::min<long>(tiles, op.grid_x);
-    CM_HIP(cm::launch_conv2(ca, op.MB, op.NB, gx, op.d_ctr + 32 * slab, st));
   } else {
     CM_HIP(cm::launch_conv(ca, op.MB, op.NB, st));
   }
@@ -1056,12 +996,18 @@ int prof_collect(cm_model *m, hipStream_t st) {
   return 0;
 }
 
+// Makes `dev` current for the duration of one C-ABI call and restores the caller's device on return.
 struct DevGuard {
-  int prev = -1;
-  explicit DevGuard(int dev) {
-    hipGetDevice(&prev);
+  int prev = -1, cur = -1;
+  explicit DevGuard(int dev) : cur(dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != dev) hipSetDevice(dev);
   }
+  ~DevGuard() {
+    if (prev >= 0 && prev != cur) hipSetDevice(prev);
+  }
+  DevGuard(const DevGuard &) = delete;
+  DevGuard &operator=(const DevGuard &) = delete;
 };
 
 int check_ready(cm_model *m, int B) {
@@ -1182,9 +1128,13 @@ int cm_model_create(const cm_unet_config *cfg, cm_model **out) {
   if (cfg->max_batch < 1) return fail("max_batch must be >= 1");
   if (cfg->num_res_blocks < 1) return fail("num_res_blocks must be >= 1");
   if ((cfg->base_channels / 2) < 2) return fail("base_channels too small for the sinusoidal table");
-  int ndev = 0;
-  CM_HIP(hipGetDeviceCount(&ndev));
-  if (cfg->device < 0 || cfg->device >= ndev) return fail("device %d not available (%d devices)", cfg->device, ndev);
+  // device < 0: host-only handle -- the state_dict plan (names, shapes, set / get) without a GPU
+  // (checkpoint tooling, the sanitizer self-test); cm_model_finalize and everything after it need a device
+  if (cfg->device >= 0) {
+    int ndev = 0;
+    CM_HIP(hipGetDeviceCount(&ndev));
+    if (cfg->device >= ndev) return fail("device %d not available (%d devices)", cfg->device, ndev);
+  }
   auto m = std::make_unique<cm_model>();
   m->cfg = *cfg;
   m->device = cfg->device;
@@ -1192,6 +1142,7 @@ int cm_model_create(const cm_unet_config *cfg, cm_model **out) {
     if (cfg->channel_mult[l] < 1 || (cfg->base_channels * cfg->channel_mult[l]) % (GN_GROUPS) != 0)
       return fail("channel_mult[%d] invalid", l);
   build_plan(m.get());
+  if (m->device < 0) { *out = m.release(); return 0; }
   DevGuard g(m->device);
   CM_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
   for (int i = 1; i < 4; ++i) {
@@ -1205,6 +1156,7 @@ int cm_model_create(const cm_unet_config *cfg, cm_model **out) {
 
 int cm_model_destroy(cm_model *m) {
   if (!m) return 0;
+  if (m->device < 0) { delete m; return 0; }
   DevGuard g(m->device);
   hipDeviceSynchronize();
   for (void *p : m->allocs) hipFree(p);
@@ -1260,6 +1212,7 @@ int cm_model_get_param(const cm_model *m, const char *name, float *h_data, int64
 int cm_model_finalize(cm_model *m) {
   if (!m) return fail("null model handle");
   if (m->finalized) return 0;
+  if (m->device < 0) return fail("host-only handle (device < 0) cannot be finalized: there is no CPU path");
   for (auto &p : m->params)
     if (!p.set) return fail("missing key in state_dict: %s", p.name.c_str());
   DevGuard g(m->device);
@@ -1604,6 +1557,17 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
     CM_HIP(hipStreamWaitEvent(st, m->ev_join[ln], 0));
   }
   CM_HIP(hipMemcpyAsync(d_out, m->xstate, B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (opts->check_finite) {
+    // sampler-output health check: a NaN / Inf from a bad checkpoint must not come back as rc 0
+    if (!m->d_nonfinite && dev_alloc(m, (void **)&m->d_nonfinite, sizeof(int))) return 1;
+    CM_HIP(cm::launch_count_nonfinite(m->xstate, (long long)(B * per), m->d_nonfinite, st));
+    int bad = 0;
+    CM_HIP(hipMemcpyAsync(&bad, m->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
+    CM_HIP(hipStreamSynchronize(st));
+    if (prof_collect(m, st)) return 1;
+    if (bad) return fail("sampling produced %d non-finite values out of %lld (check_finite)", bad, (long long)(B * per));
+    return 0;
+  }
   return prof_collect(m, st);
 }
 
@@ -1687,8 +1651,8 @@ int cm_profile_report(cm_model *m, char *buf, int64_t capacity) {
       const double tf = op.flops_per_sample * op.prof_B / (us * 1e-6) / 1e12;
       snprintf(line, sizeof(line), "%-52s %9.1f us %7.2f TF %8.1f MF/sample B%d ks%d  %s%d NB%d box %dx%dx%dx%d grid %dx%d CK%d lds %zu\n", op.label.c_str(), us, tf,
                op.flops_per_sample / 1e6, op.prof_B, op.ks,
-               op.v2 ? "v2 MB" : "MB", op.MB, op.NB, a.bs, a.bz, a.by, a.bx, op.v2 ? op.grid_x : a.nts * a.ntz * a.nty * a.ntx,
-               (a.Co + 32 * op.NB - 1) / (32 * op.NB), a.CK, op.v2 ? cm::conv2_lds_bytes(a, op.MB, op.NB) : cm::conv_lds_bytes(a, op.MB, op.NB));
+               "MB", op.MB, op.NB, a.bs, a.bz, a.by, a.bx, a.nts * a.ntz * a.nty * a.ntx,
+               (a.Co + 32 * op.NB - 1) / (32 * op.NB), a.CK, cm::conv_lds_bytes(a, op.MB, op.NB));
     } else {
       snprintf(line, sizeof(line), "%-52s %9.1f us\n", op.label.c_str(), us);
     }
@@ -1734,7 +1698,7 @@ int cm_debug_conv_info(const cm_model *m, int32_t index, char *buf, int64_t capa
   const cm::ConvArgs &a = op.ca;
   snprintf(buf, (size_t)capacity, "conv %s %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d", op.label.c_str(), a.ntaps, a.stride, a.par,
            a.C0 + a.C1, a.Co, a.Zo, a.Yo, a.Xo, op.NB, op.MB, a.bz, a.by, a.bx, op.ks,
-           (op.small_n ? 1 : 0) | (op.v2 ? 2 : 0) | (op.stat_act ? 4 : 0) | (op.skip_if_fused ? 8 : 0) | (a.CK == 32 ? 16 : 0));
+           (op.small_n ? 1 : 0) | (op.stat_act ? 4 : 0) | (op.skip_if_fused ? 8 : 0) | (a.CK == 32 ? 16 : 0));
   return 0;
 }
 
@@ -1745,7 +1709,7 @@ int cm_debug_time_conv(cm_model *m, int32_t index, int32_t MB, int32_t bz, int32
   if (check_ready(m, B)) return 1;
   if (!us || index < 0 || index >= (int)m->ops.size() || iters < 1) return fail("bad argument");
   Op &op = m->ops[index];
-  if (op.kind != OP_CONV || op.v2) return fail("op %d is not a tunable convolution", index);
+  if (op.kind != OP_CONV) return fail("op %d is not a tunable convolution", index);
   if (op.tuned_B < 0) return fail("run a forward first");
   DevGuard g(m->device);
   hipStream_t st = m->stream;

@@ -64,6 +64,17 @@ class DDPM_model:
         self.res = cfgmod.resolve(cfg, arch)
         self.denoiser = self._get_denoiser()
         self._sample_calls = 0
+        self.dp_rank, self.dp_world = 0, 1   # data-parallel training position (set_data_parallel)
+
+    def set_data_parallel(self, rank: int, world: int):
+        """Data-parallel training (one process per GPU): rank r draws its own timesteps and -- through the
+        global sample index rank * batch + b -- its own eps and Dropout3d masks; epoch-level decisions
+        (ReduceLROnPlateau, NaN stop, best-loss checkpoint) are taken on the loss averaged over ranks, so every
+        replica cuts the rate and stops in the same epoch."""
+        if not (0 <= int(rank) < int(world)):
+            raise ValueError(f"rank {rank} outside world of {world}")
+        self.dp_rank, self.dp_world = int(rank), int(world)
+        return self
 
     def _get_denoiser_cfg(self):
         """ddpm.py:65-72; tolerant of the older schema generations."""
@@ -180,10 +191,11 @@ class DDPM_model:
     # ------------------------------------------------------------------------------
     def _train_step(self, future, past, forward_sampler: DDPM, *, t=None, noise=None, drop_masks=None,
                     rng: Optional[np.random.Generator] = None):
-        """Forward half of ddpm.py:111-121: t ~ U{0..T-1}, (x_t, eps) = q_sample(future, t),
-        eps_hat = UNet(x_t, t, past) with Dropout3d active, loss = mse(eps_hat, eps).
-        Returns (loss, eps_hat).  The backward pass and the Adam update (ddpm.py:142-144) are
-        NOT implemented in this build: the value is the loss of the current weights only."""
+        """ddpm.py:111-121 as the reference defines it (loss only): t ~ U{0..T-1}, (x_t, eps) = q_sample(future, t),
+        eps_hat = UNet(x_t, t, past) with Dropout3d active, loss = mse(eps_hat, eps).  Returns (loss, eps_hat).
+        The backward pass and the Adam update of ddpm.py:142-144 run inside `_train_one_epoch` (one native
+        cm_train_step per batch); this method is the stand-alone loss evaluation with injectable t / noise /
+        masks that the parity tests use."""
         future = np.ascontiguousarray(future, dtype=np.float32)
         B = future.shape[0]
         if t is None:
@@ -214,6 +226,8 @@ class DDPM_model:
         net = self.denoiser
         B, _, H, W, F = future.shape
         net.ensure(H, W, int(past.shape[4]), F, B)
+        if self.dp_world > 1 and getattr(net, "_sample_base", None) != self.dp_rank * B:
+            net.set_sample_base(self.dp_rank * B)
         if not getattr(net, "_train_ready", False):
             s = self._solver()
             net.train_init(lr=s["lr"], betas=s["betas"], weight_decay=s["weight_decay"])
@@ -226,7 +240,8 @@ class DDPM_model:
         noise, train-mode forward, MSE, backward, Adam -- one native call per batch.  `grad_sync`, when
         given, is called between backward and update (data-parallel gradient averaging).
         Returns the mean batch loss (MeanMetric)."""
-        rng = rng or np.random.default_rng(self.seed + epoch)
+        # one stream of timesteps per (seed, epoch, rank): replicas must not train on identical draws
+        rng = rng or np.random.default_rng([self.seed + epoch, self.dp_rank] if self.dp_world > 1 else self.seed + epoch)
         total, count = 0.0, 0
         for past, future in loader:
             past = np.ascontiguousarray(past, dtype=np.float32)
@@ -267,9 +282,13 @@ class DDPM_model:
         checkpoint.save_checkpoint(net.state_dict(), path, opt_state=opt)
         return path
 
-    def train(self, batched_train_data, baseline_ckpt=None, *, log=None, grad_sync=None, save=True):
+    def train(self, batched_train_data, baseline_ckpt=None, *, log=None, grad_sync=None, save=True, loss_sync=None):
         """ddpm.py:156-202: epochs of _train_one_epoch, ReduceLROnPlateau on the epoch loss, NaN early
-        stop, best-loss checkpoint tagged "000" and CHECKPOINTS_TO_KEEP random late epochs."""
+        stop, best-loss checkpoint tagged "000" and CHECKPOINTS_TO_KEEP random late epochs.
+        Data-parallel: `grad_sync` averages the gradients every step and `loss_sync` (float -> float, e.g.
+        distributed.mean_over_ranks) averages the epoch loss, so that the scheduler, the NaN stop and the
+        checkpoint decisions are identical on every rank (a rank that stopped alone would leave the others
+        blocked in the gradient all-reduce)."""
         import logging
         forward_sampler = DDPM(timesteps=max(2, self.res.timesteps), scale=self.res.scale, device=self.device)
         if baseline_ckpt is not None:
@@ -286,6 +305,8 @@ class DDPM_model:
         history = []
         for epoch in range(1, epochs + 1):
             epoch_loss = self._train_one_epoch(forward_sampler, batched_train_data, epoch, grad_sync=grad_sync)
+            if loss_sync is not None:
+                epoch_loss = float(loss_sync(epoch_loss))   # NaN on any rank -> NaN everywhere
             history.append(epoch_loss)
             if log:
                 log({"train_loss": epoch_loss, "epoch": epoch, "lr": self._lr})

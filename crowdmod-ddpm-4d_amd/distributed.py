@@ -70,6 +70,21 @@ def init_process_group(backend: str = None):
     dist.init_process_group(backend=backend)
 
 
+def mean_over_ranks(value: float, group=None) -> float:
+    """Mean of a host scalar over the ranks (fp64 all-reduce; NaN on any rank gives NaN everywhere): the
+    epoch loss that drives ReduceLROnPlateau / the NaN stop in data-parallel training."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return float(value)
+    dev = "cpu"
+    if dist.get_backend(group) == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item()) / dist.get_world_size(group)
+
+
 class _DevView:
     """Zero-copy torch view of a raw device allocation through __cuda_array_interface__."""
 

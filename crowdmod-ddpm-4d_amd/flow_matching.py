@@ -75,7 +75,7 @@ class FM_model(DDPM_model):
             w_fn = self.w_type_fns[self.w_type]
         except KeyError:
             raise ValueError(f"Unsupported W_TYPE '{self.w_type}'. Available: {list(self.w_type_fns.keys())}")
-        rng = rng or np.random.default_rng(self.seed + epoch)
+        rng = rng or np.random.default_rng([self.seed + epoch, self.dp_rank] if self.dp_world > 1 else self.seed + epoch)
         total, count = 0.0, 0
         for past, future in loader:
             past = np.ascontiguousarray(past, dtype=np.float32)
@@ -83,7 +83,8 @@ class FM_model(DDPM_model):
             self._ensure_training(past, x1)
             B = x1.shape[0]
             self._fm_calls += 1
-            x0b = prng.normal(self.seed, f"fm/x0/{self._fm_calls}", x1.size).reshape(x1.shape) if x0 is None else x0
+            tag = f"fm/x0/{self._fm_calls}" + (f"/r{self.dp_rank}" if self.dp_world > 1 else "")   # own x0 per rank
+            x0b = prng.normal(self.seed, tag, x1.size).reshape(x1.shape) if x0 is None else x0
             tb = rng.random(B, dtype=np.float32) if t is None else np.asarray(t, dtype=np.float32)
             tv = tb.reshape(-1, 1, 1, 1, 1)
             xt, u_target = w_fn(np.asarray(x0b, dtype=np.float32), x1, tv)
@@ -104,10 +105,11 @@ class FM_model(DDPM_model):
                                           epoch_tag, self.w_type)
         return os.path.join(self.cfg.DATA_FS.SAVE_DIR, name)
 
-    def train(self, batched_train_data, baseline_ckpt=None, *, log=None, grad_sync=None, save=True):
+    def train(self, batched_train_data, baseline_ckpt=None, *, log=None, grad_sync=None, save=True, loss_sync=None):
         keep = int(self.cfg.MODEL.FM.get("CHECKPOINTS_TO_KEEP", 0) or 0)
         self._keep_override = keep
-        return super().train(batched_train_data, baseline_ckpt, log=log, grad_sync=grad_sync, save=save)
+        return super().train(batched_train_data, baseline_ckpt, log=log, grad_sync=grad_sync, save=save,
+                             loss_sync=loss_sync)
 
     # -- sampling entry (flow_matching.py:250-292) ------------------------------------------
     def sampling(self, batched_test_data, plotType=None, model_fullname=None, plotMprop=None, plotPast=None,

@@ -16,6 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM_LIB_PATH") or os.path.join(_HERE, "libcrowdmod_hip.so")  # override: A/B of two builds
 MAX_LEVELS = 8
+ABI_VERSION = 3   # CM_ABI_VERSION of include/crowdmod_hip.h
 
 
 class NativeError(RuntimeError):
@@ -36,7 +37,7 @@ class cm_sample_opts(C.Structure):
     _fields_ = [
         ("sampler", C.c_int32), ("guidance", C.c_int32), ("lambda_guidance", C.c_float),
         ("ddim_sigma", C.c_float), ("ddim_divider", C.c_int32), ("first_steps", C.c_int32),
-        ("seed", C.c_uint64), ("sample_id_base", C.c_int64), ("use_graph", C.c_int32), ("reserved", C.c_int32),
+        ("seed", C.c_uint64), ("sample_id_base", C.c_int64), ("use_graph", C.c_int32), ("check_finite", C.c_int32),
         ("fm_steps", C.c_int32), ("fm_time_max_pos", C.c_int32),
     ]
 
@@ -93,6 +94,7 @@ SIGNATURES = {
                                      C.POINTER(C.c_float)]),
     "cm_train_init": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     "cm_train_set_lr": (C.c_int, [_P, C.c_float]),
+    "cm_train_set_sample_base": (C.c_int, [_P, C.c_int64]),
     "cm_train_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_float), C.c_int32, C.c_int32, _P]),
     "cm_train_step_xt": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_float), C.c_int32, C.c_int32, _P]),
     "cm_train_get_grad": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
@@ -139,7 +141,7 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.cm_abi_version() != 2:
+    if L.cm_abi_version() != ABI_VERSION:
         raise NativeError("libcrowdmod_hip.so ABI version mismatch")
     _lib = L
     return L

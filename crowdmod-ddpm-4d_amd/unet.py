@@ -83,12 +83,20 @@ class UNet:
                 if tuple(got[k].shape) != tuple(shp):
                     raise RuntimeError(f"size mismatch for {k}: got {tuple(got[k].shape)}, expected {tuple(shp)}")
                 self._params[k] = got[k]
-        self._release()
+        self._carry_opt = None
+        self._release(keep_training=False)
         return self
 
     # -- native handle -------------------------------------------------------------
-    def _release(self):
+    def _release(self, keep_training: bool = True):
+        """Destroy the native handle.  A handle that has trained holds the only copy of the master weights
+        and the Adam moments: they are pulled back to the host first and re-installed by the next ensure()
+        (keep_training=False -- load_state_dict -- discards them on purpose)."""
         if self._handle is not None:
+            if getattr(self, "_train_ready", False) and keep_training:
+                self.sync_trained()
+                hp = self._train_hparams
+                self._carry_opt = (self.optimizer_state_dict(hp["lr"], hp["betas"], hp["eps"], hp["weight_decay"]), hp)
             native.lib().cm_model_destroy(self._handle)
             self._handle = None
             self._geom = None
@@ -96,7 +104,7 @@ class UNet:
 
     def __del__(self):
         try:
-            self._release()
+            self._release(keep_training=False)
         except Exception:
             pass
 
@@ -129,6 +137,13 @@ class UNet:
             L.cm_model_destroy(h)
             raise
         self._handle, self._geom = h, geom
+        carry = getattr(self, "_carry_opt", None)
+        if carry is not None:
+            # the handle this one replaces was training: continue from its optimizer state
+            opt, hp = carry
+            self._carry_opt = None
+            self.train_init(lr=hp["lr"], betas=hp["betas"], eps=hp["eps"], weight_decay=hp["weight_decay"])
+            self.load_optimizer_state_dict(opt)
         return h
 
     # -- forward -------------------------------------------------------------------
@@ -213,9 +228,21 @@ class UNet:
         native.check(native.lib().cm_train_init(self._handle, float(lr), float(betas[0]), float(betas[1]), float(eps),
                                                 float(weight_decay), float(self.cfg.dropout_rate)))
         self._train_ready = True
+        self._train_hparams = {"lr": float(lr), "betas": (float(betas[0]), float(betas[1])), "eps": float(eps),
+                               "weight_decay": float(weight_decay)}
+        if getattr(self, "_sample_base", 0):
+            native.check(native.lib().cm_train_set_sample_base(self._handle, int(self._sample_base)))
 
     def set_lr(self, lr: float):
         native.check(native.lib().cm_train_set_lr(self._handle, float(lr)))
+        self._train_hparams["lr"] = float(lr)
+
+    def set_sample_base(self, sample_id_base: int):
+        """Data-parallel training: global index of this rank's sample 0, so that the device-drawn eps and
+        Dropout3d masks differ between ranks (and do not depend on how the job is sharded)."""
+        self._sample_base = int(sample_id_base)
+        if getattr(self, "_train_ready", False):
+            native.check(native.lib().cm_train_set_sample_base(self._handle, self._sample_base))
 
     def _mask_rows(self, B, drop_masks):
         layout, width = self.dropout_layout()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 2
+#define CM_ABI_VERSION 3
 #define CM_MAX_LEVELS 8
 
 typedef struct cm_model cm_model;       /* UNet denoiser: weights + workspace   */
@@ -50,7 +50,8 @@ typedef struct cm_unet_config {
   int32_t rows, cols;                     /* MACROPROPS.ROWS / COLS             */
   int32_t past_len, future_len;           /* DATASET.PAST_LEN / FUTURE_LEN      */
   int32_t max_batch;                      /* workspace is sized for this batch  */
-  int32_t device;                         /* HIP device ordinal                 */
+  int32_t device;                         /* HIP device ordinal; < 0: host-only handle (state_dict plan:
+                                             names, shapes, set / get) that can never be finalized      */
 } cm_unet_config;
 
 /* ---- errors / info ------------------------------------------------------ */
@@ -95,7 +96,8 @@ int cm_unet_forward_host(cm_model *m, const float *h_future, const int64_t *h_t,
  * keep-mask/(1-p) value per (sample, ResnetBlock, channel).  d_dropmask [B][width] injects the
  * masks (width from cm_model_dropout_width: the blocks in state_dict order, Cout entries each);
  * NULL draws them from the device Philox stream (seed, sample_id_base + b).  Used by
- * DDPM_model._train_step (ddpm.py:111-121); the backward pass is not part of this build yet. */
+ * DDPM_model._train_step (ddpm.py:111-121) when only the prediction is wanted; the full step
+ * (loss, backward, Adam) is cm_train_step below. */
 int cm_model_dropout_width(const cm_model *m, int32_t *width);
 int cm_unet_forward_train(cm_model *m, const float *d_future, const int64_t *d_t, const float *d_past,
                           const float *d_dropmask, float p, uint64_t seed, int64_t sample_id_base,
@@ -151,7 +153,10 @@ typedef struct cm_sample_opts {
   int64_t sample_id_base; /* global index of sample 0 (batch sharding)           */
   int32_t use_graph;      /* 1: capture one step as a hipGraph (per-step scalars in a device table) and replay
                              it for the remaining steps; the call then returns after the loop has finished   */
-  int32_t reserved;
+  int32_t check_finite;   /* 1: after the last step count the non-finite elements of x_0; the call then returns
+                             after the loop has finished, with a non-zero status (and the count in
+                             cm_last_error) if any element is NaN / Inf -- the sampler-output health check
+                             (the reference's analogue is the NaN stop of its training loop, ddpm.py:183-192) */
   /* CM_SAMPLER_FM_EULER -- FM_model.sampling_with_euler (models/flow_matching/flow_matching.py:203-224):
    * x <- x + (1/N) u(x, idx_i, past) for t_i = linspace(0,1,N)[i], idx_i = clamp(t_i * TIME_MAX_POS, 0,
    * TIME_MAX_POS-1) truncated; the schedule handle is not consulted. */
@@ -216,6 +221,10 @@ int cm_debug_time_conv(cm_model *m, int32_t index, int32_t MB, int32_t bz, int32
 int cm_train_init(cm_model *m, float lr, float beta1, float beta2, float eps, float weight_decay,
                   float dropout_rate /* cfg DROPOUT_RATE: nn.Dropout3d(p), layers.py:42 */);
 int cm_train_set_lr(cm_model *m, float lr);
+/* Data-parallel training: global index of this rank's sample 0 (rank * per-rank batch).  The device
+ * Philox streams of eps and of the Dropout3d masks are addressed by (seed, step, GLOBAL sample index), so
+ * ranks draw different noise and a job's samples draw the same numbers however it is sharded.  Default 0. */
+int cm_train_set_sample_base(cm_model *m, int64_t sample_id_base);
 /* One step on device buffers:
  *   x_t = q_sample(d_future, d_t, d_eps)          (forward.py:29-35 with the caller's noise)
  *   eps_hat = UNet(x_t, d_t, d_past) in train mode (Dropout3d masks: d_dropmask [B][width] or

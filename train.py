@@ -91,11 +91,13 @@ def main():
     logging.info("=======>>>> Init training for %s dataset with %s architecture: %d windows, %d batches/epoch/rank",
                  cfg.DATASET.get("NAME", "?"), args.arch, past.shape[0], len(loader))
 
-    grad_sync = None
+    grad_sync = loss_sync = None
     if world > 1:
         from crowdmod_ddpm_4d_amd import distributed as cdist
         cdist.init_process_group()
         grad_sync = cdist.GradAverager()
+        loss_sync = cdist.mean_over_ranks
+        model.set_data_parallel(rank, world)
     save_dir = cfg.DATA_FS.SAVE_DIR
     os.makedirs(save_dir, exist_ok=True)
     logf = open(os.path.join(save_dir, "train_log.jsonl"), "a") if rank == 0 else None
@@ -106,7 +108,7 @@ def main():
             logf.write(json.dumps(rec) + "\n")
             logf.flush()
 
-    model.train(loader, args.baseline_ckpt, log=log, grad_sync=grad_sync, save=(rank == 0))
+    model.train(loader, args.baseline_ckpt, log=log, grad_sync=grad_sync, save=(rank == 0), loss_sync=loss_sync)
     logging.info("Trained model %s saved in %s", args.arch, save_dir)
 
 
