@@ -676,8 +676,14 @@ static void conv_dbg_report(const ConvArgs &a, int MB, int NB, int F, dim3 grid,
           MB, NB, F, a.C0 + a.C1, a.Co, a.ntaps, a.ks, grid.x, grid.y, grid.z, (t1 - t0) / 100.0, ph[0] / 100, ph[1] / 100, ph[2] / 100, ph[3] / 100);
 }
 
+int conv_dbg_override = -1;
+int conv_dbg_flags() {
+  static const int env = getenv("CM_CONV_DBG") ? atoi(getenv("CM_CONV_DBG")) : 0;  // ablation switches (perf studies only)
+  return conv_dbg_override >= 0 ? conv_dbg_override : env;
+}
+
 hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
-  static const int dbg = getenv("CM_CONV_DBG") ? atoi(getenv("CM_CONV_DBG")) : 0;  // ablation switches (perf studies only)
+  const int dbg = conv_dbg_flags();
   static const int stg = getenv("CM_CONV_STAGGER") ? atoi(getenv("CM_CONV_STAGGER")) : -1;
   ConvArgs a = a_in;
   a.dbg = dbg;

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvArgs a, cons
   const int a_bz = SPEC ? BZ : a.bz, a_by = SPEC ? BY : a.by, a_bx = SPEC ? BX : a.bx, a_CK = SPEC ? 32 : a.CK;
   const int tid = threadIdx.x;
   int tile = blockIdx.x;
-  if (!(gridDim.x & 7)) tile = (tile & 7) * (int)(gridDim.x >> 3) + (tile >> 3);  // XCD-aware order (see cm_conv.hip)
+  if (!(gridDim.x & 7) && !(a.dbg & 4096)) tile = (tile & 7) * (int)(gridDim.x >> 3) + (tile >> 3);  // XCD-aware order (see cm_conv.hip)
   const int tx = tile % a.ntx; tile /= a.ntx;
   const int ty = tile % a.nty; tile /= a.nty;
   const int tz = tile % a.ntz;
@@ -155,7 +155,9 @@ size_t conv_smalln_lds(const ConvArgs &a, int MB) {
   return (HV * (a.CK + 4) + (size_t)27 * a.CK * nco + (size_t)(256 / TM) * TM * nco) * sizeof(float);
 }
 
-hipError_t launch_conv_smalln(const ConvArgs &a, int MB, const float *wsm, hipStream_t st) {
+hipError_t launch_conv_smalln(const ConvArgs &a_in, int MB, const float *wsm, hipStream_t st) {
+  ConvArgs a = a_in;
+  a.dbg = conv_dbg_flags();
   if (!conv_smalln_ok(a, MB)) return hipErrorInvalidValue;
   const int TM = 32 * MB;
   const size_t lds = conv_smalln_lds(a, MB);

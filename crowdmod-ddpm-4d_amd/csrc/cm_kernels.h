@@ -68,6 +68,10 @@ struct ConvArgs {
   int stagger;         // start delay (in 64-cycle units) applied to every other first-wave workgroup
 };
 
+// Diagnostic switches of the conv kernels (ConvArgs::dbg): CM_CONV_DBG from the environment, or the value
+// set through cm_debug_conv_flags (>= 0) -- tests flip the XCD tile remap inside one process with it.
+extern int conv_dbg_override;
+int conv_dbg_flags();
 size_t conv_lds_bytes(const ConvArgs &a, int MB, int NB);
 // Host-side builders of ConvArgs::hvtab / mtab for the box stored in `a`.
 void conv_build_tables(const ConvArgs &a, int MB, int *hvtab /*[conv_halo_voxels]*/, int *mtab /*[32*MB]*/);
@@ -114,6 +118,21 @@ hipError_t launch_time_mlp(const float *table, const float *W1, const float *b1,
                            float *out, const long long *rowidx, hipStream_t st);
 // softmax(q k^T / sqrt(d)) v per (sample, head); qkv channels-last [B][S][3E]
 hipError_t launch_attn_core(const float *qkv, float *out, int B, int S, int E, int heads, hipStream_t st);
+
+// Fused AttentionBlock (cm_attn_block.hip): GroupNorm + in-projection + softmax(q k^T) v + partial out-projection
+// per (head, sample); the heads are summed by launch_ksplit_combine (S = heads, stride = B * S * E).
+struct AttnBlockArgs {
+  const float *x;                 // [B][S][E] block input (channels-last), also the residual
+  const float *gamma, *beta;      // [E] attention.group_norm affine
+  const float *w_in, *b_in;       // mhsa.in_proj_weight [3E][E] (reference layout), in_proj_bias [3E]
+  const float *w_out;             // mhsa.out_proj.weight [E][E] (reference layout)
+  float *part;                    // [heads][B][S][E] partial out-projections
+  int B, S, E, heads, groups;
+  float eps;
+};
+bool attn_block_ok(int S, int E, int heads, int groups);
+size_t attn_block_lds_bytes(int S, int E, int heads);
+hipError_t launch_attn_block(const AttnBlockArgs &a, hipStream_t st);
 
 // Per-step scalars of the sampling loop as a device table, so that one captured graph of a step can be
 // replayed for every step: the step kernels read row tab[*kctr]; step_begin advances the counter.

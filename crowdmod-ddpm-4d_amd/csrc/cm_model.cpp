@@ -80,7 +80,7 @@ struct BlockDesc {
   int cin, cout, attention, skip, level;
 };
 
-enum OpKind { OP_CONV, OP_STATS, OP_GNFIN, OP_ATTN };
+enum OpKind { OP_CONV, OP_STATS, OP_GNFIN, OP_ATTN, OP_ATTNBLK };
 
 struct Op {
   OpKind kind;
@@ -125,6 +125,13 @@ struct Op {
   const float *qkv = nullptr;
   float *aout = nullptr;
   int S = 0, E = 0;
+  // fused attention block (inference plan): replaces the four ops flagged `in_attn_block` in front of it
+  bool in_attn_block = false;
+  const Act *ab_x = nullptr;      // block input (and residual)
+  Act *ab_out = nullptr;          // block output (statistics producer)
+  int ab_gn = -1, ab_qkv = -1, ab_outc = -1;   // indices of the ops whose device parameters it reads
+  float *d_win = nullptr, *d_wout = nullptr;   // reference-layout copies of in_proj_weight / out_proj.weight
+  std::string win_name, wout_name;
 };
 
 }  // namespace
@@ -738,6 +745,26 @@ int build_ops(cm_model *m) {
       if (add_conv(m, co)) return 1;
       add_stats(m, h3);
       *result = h3;
+      // Inference plan: the whole AttentionBlock as one launch per (head, sample) + the head combine
+      // (cm_attn_block.hip) when the sample's tokens fit the LDS-resident design; the four generic ops above
+      // stay in the list for the training forward (their activations feed the backward pass) and as fallback.
+      const int nops = (int)m->ops.size();
+      if (cm::attn_block_ok(qkv->V(), b.cout, ATTN_HEADS, GN_GROUPS) && !getenv("CM_NO_FUSED_ATTN") && !getenv("CM_NO_FUSED_STATS")) {
+        Op fb;
+        fb.kind = OP_ATTNBLK; fb.cls = K_ATTN; fb.label = ap + " (fused block)";
+        fb.ab_x = h2; fb.ab_out = h3; fb.S = qkv->V(); fb.E = b.cout;
+        fb.ab_gn = nops - 4; fb.ab_qkv = nops - 3; fb.ab_outc = nops - 1;
+        if (m->ops[fb.ab_gn].kind != OP_GNFIN || m->ops[fb.ab_qkv].kind != OP_CONV || m->ops[nops - 2].kind != OP_ATTN ||
+            m->ops[fb.ab_outc].kind != OP_CONV)
+          return fail("attention block plan out of order");
+        fb.win_name = ap + ".mhsa.in_proj_weight"; fb.wout_name = ap + ".mhsa.out_proj.weight";
+        if (upload(m, P(m, fb.win_name).host, &fb.d_win)) return 1;
+        if (upload(m, P(m, fb.wout_name).host, &fb.d_wout)) return 1;
+        for (int i = nops - 4; i < nops; ++i) m->ops[i].in_attn_block = true;
+        const size_t need = (size_t)ATTN_HEADS * m->cfg.max_batch * fb.S * fb.E;
+        m->ks_scratch_floats = std::max(m->ks_scratch_floats, need);
+        m->ops.push_back(fb);
+      }
     }
     return 0;
   };
@@ -930,6 +957,8 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
 int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
   for (size_t oi = 0; oi < m->ops.size(); ++oi) {
     Op &op = m->ops[oi];
+    // the fused attention block runs in the inference plan, its four generic ops in the training forward
+    if (op.kind == OP_ATTNBLK ? m->train_fwd : (op.in_attn_block && !m->train_fwd)) continue;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->profile) {
       CM_HIP(hipEventCreate(&e0));
@@ -962,6 +991,27 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
         CM_HIP(cm::launch_attn_core(op.qkv + (size_t)b0 * op.S * 3 * op.E, op.aout + (size_t)b0 * op.S * op.E, B, op.S,
                                     op.E, ATTN_HEADS, st));
         break;
+      case OP_ATTNBLK: {
+        const Op &gop = m->ops[op.ab_gn], &qop = m->ops[op.ab_qkv], &oop = m->ops[op.ab_outc];
+        float *scratch = m->ks_scratch + (size_t)slab * m->ks_scratch_floats;
+        const size_t xoff = (size_t)b0 * op.S * op.E;
+        cm::AttnBlockArgs aa{};
+        aa.x = op.ab_x->d + xoff; aa.gamma = gop.gamma; aa.beta = gop.beta;
+        aa.w_in = op.d_win; aa.b_in = qop.ca.bias; aa.w_out = op.d_wout;
+        aa.part = scratch; aa.B = B; aa.S = op.S; aa.E = op.E; aa.heads = ATTN_HEADS; aa.groups = GN_GROUPS; aa.eps = GN_EPS;
+        CM_HIP(cm::launch_attn_block(aa, st));
+        cm::CombineArgs cb{};
+        cb.part = scratch; cb.S = ATTN_HEADS; cb.stride = (long long)B * op.S * op.E;
+        cb.bias = oop.ca.bias; cb.temb = nullptr; cb.tidx = m->tbuf;
+        cb.resid = aa.x; cb.res_cs = op.E;
+        cb.out = op.ab_out->d + xoff; cb.C = op.E; cb.V = op.S; cb.B = B;
+        cb.nslots = (op.S + 31) / 32;
+        cb.stat_part = op.ab_out->part + (size_t)b0 * cb.nslots * cb.C * 2;
+        cb.stat_cnt = op.ab_out->cnt + (size_t)b0 * cb.nslots;
+        op.ab_out->nslots = cb.nslots;
+        CM_HIP(cm::launch_ksplit_combine(cb, st));
+        break;
+      }
     }
     if (m->profile) {
       CM_HIP(hipEventRecord(e1, st));
@@ -1684,6 +1734,11 @@ int cm_frame_metrics(int32_t device, const float *d_pred, const float *d_gt, int
 }
 
 // ---- tile tuner hooks (tools/tune_tiles.py; not used by the product path) --------------------
+int cm_debug_conv_flags(int32_t flags) {
+  cm::conv_dbg_override = flags;   // < 0: back to the CM_CONV_DBG environment value
+  return 0;
+}
+
 int cm_debug_conv_count(const cm_model *m, int32_t *count) {
   if (!m || !m->finalized || !count) return fail("model not finalized");
   *count = (int32_t)m->ops.size();

@@ -208,6 +208,9 @@ int cm_frame_metrics(int32_t device, const float *d_pred, const float *d_gt, int
 
 /* ---- tuning hooks (tools/tune_tiles.py): time one convolution of the plan with an explicit tile
  * geometry.  Diagnostics only -- the product path never calls them. */
+/* Process-wide diagnostic switches of the conv kernels (the CM_CONV_DBG bit mask of DESIGN.md; 4096 = XCD tile
+ * remap off); flags < 0 returns to the environment value.  Results are only defined for 0 / 4096 / 2048 / 512. */
+int cm_debug_conv_flags(int32_t flags);
 int cm_debug_conv_count(const cm_model *m, int32_t *count);
 int cm_debug_conv_info(const cm_model *m, int32_t index, char *buf, int64_t capacity);
 int cm_debug_time_conv(cm_model *m, int32_t index, int32_t MB, int32_t bz, int32_t by, int32_t bx,

@@ -14,6 +14,9 @@ What is captured:
   train.npz         loss + per-tensor gradient norms of one training step
   metrics.npz       PSNR / masked PSNR / relative density / TV tables of the reference's MetricsGenerator
   fm.npz            flow matching: Euler sampling + one training step per probability path
+  loop_grids.npz    (--only loop_grids) _generate_ddpm T=50 on the HERMES-CR-120 (28x24) and 2x ATC (24x72) grids,
+                    _generate_ddim divider 50 on CR-120
+  train_full_cr120.npz  (--only train_grids) full-width training step on the CR-120 grid
 
 Weights and inputs are NOT stored: both sides regenerate them bit-identically
 from the integer PRNG (crowdmod-ddpm-4d_amd/prng.py, spec.init_params).
@@ -199,18 +202,20 @@ def loop_noise(tag, B, per, t):
     return prng.normal_per_sample(SEED_X, f"z/{tag}", np.arange(B), per, step=t)
 
 
-def gen_loop(out):
+def gen_loop(out, grids_only=False):
     AttrDict = _placeholders()
     import yaml
     from models.diffusion import ddpm as RD
     cfg_yaml = AttrDict(yaml.safe_load(open(os.path.join(REF, "config", "ATC.yml"))))
-    C, H, W, P, F, B = 3, 12, 36, 5, 3, 2
+    C, P, F, B = 3, 5, 3, 2
     ucfg = full_cfg(C)
     params = spec.init_params(ucfg, SEED_W)
     d = {}
 
-    def run(tag, T, sampler, guidance="None", lam=0.0, divider=None, sigma=None, keep=()):
+    def run(tag, T, sampler, guidance="None", lam=0.0, divider=None, sigma=None, keep=(), grid=(12, 36)):
+        H, W = grid
         cfg = AttrDict(yaml.safe_load(open(os.path.join(REF, "config", "ATC.yml"))))
+        cfg.MACROPROPS.ROWS, cfg.MACROPROPS.COLS = H, W
         cfg.MODEL.DDPM.TIMESTEPS = T
         cfg.MODEL.DDPM.GUIDANCE = guidance
         cfg.MODEL.DDPM.LAMBDA_GUIDANCE = lam
@@ -260,6 +265,14 @@ def gen_loop(out):
             d[f"{tag}/x_after_t{t}"] = v
         print("loop", tag, float(x.abs().max()))
 
+    if grids_only:
+        # round 2: the reference's own loop on the other two grids of BASELINE.json (configs[3] HERMES-CR-120 28x24,
+        # configs[4] 2x ATC 24x72) -- their own file, so that loop.npz keeps regenerating bit for bit
+        run("cr120_ddpm50", 50, "DDPM", grid=FULL_GRIDS["cr120"])
+        run("atc2x_ddpm50", 50, "DDPM", grid=FULL_GRIDS["atc2x"])
+        run("cr120_ddim1000_div50", 1000, "DDIM", divider=50, sigma=0.001, grid=FULL_GRIDS["cr120"])
+        np.savez_compressed(os.path.join(out, "loop_grids.npz"), **d)
+        return
     run("ddpm50", 50, "DDPM")
     run("ddpm20_sparsity", 20, "DDPM", guidance="Sparsity", lam=0.004)
     run("ddim1000_div100", 1000, "DDIM", divider=100, sigma=0.001)
@@ -342,21 +355,23 @@ def gen_train(out):
     print("train loss", float(loss), "second step", float(loss2))
 
 
-def gen_train_full(out):
+def gen_train_full(out, grid="atc"):
     """Training step of the FULL-width model (base 32, ATC grid 12x36, B = 2): loss and the gradient norm of
     every trainable tensor -- exercises the 32-channel-chunk kernels, the K-split quarter-resolution layers and
-    the parity-form upsample convs of the backward pass, which the narrow model does not reach."""
+    the parity-form upsample convs of the backward pass, which the narrow model does not reach.
+    grid="cr120" (round 2): the same on the HERMES-CR-120 grid 28x24 -> train_full_cr120.npz."""
     import torch.nn as nn
     from models.backbones import layers as RL
     from models.diffusion.forward import ForwardSampler
     C, B = 3, 2
-    H, W = FULL_GRIDS["atc"]
+    H, W = FULL_GRIDS[grid]
     P, F = 5, 3
     cfg = full_cfg(C)
     params = spec.init_params(cfg, SEED_W)
     net = ref_unet(cfg, params).train()
-    past, fut = synth_inputs(B, C, H, W, P, F, "trainfull")
-    eps = prng.normal(SEED_X, "trainfull/eps", fut.size).reshape(fut.shape)
+    sfx = "" if grid == "atc" else "/" + grid
+    past, fut = synth_inputs(B, C, H, W, P, F, "trainfull" + sfx)
+    eps = prng.normal(SEED_X, "trainfull/eps" + sfx, fut.size).reshape(fut.shape)
     t = np.array([17, 803], dtype=np.int64)
 
     class FixedDrop(nn.Module):
@@ -389,8 +404,8 @@ def gen_train_full(out):
     for k in ("decoder_blocks.5.upsample.1.weight", "bottleneck_blocks.0.conv_1.weight"):
         g = dict(net.named_parameters())[k].grad.numpy()
         d[f"gslice/{k}"] = g[:4, :4].copy()      # a 4 x 4 x 3 x 3 x 3 corner of two large gradients
-    np.savez_compressed(os.path.join(out, "train_full.npz"), **d)
-    print("train_full loss", float(loss.item()), "tensors", len(d) - 2)
+    np.savez_compressed(os.path.join(out, "train_full.npz" if grid == "atc" else f"train_full_{grid}.npz"), **d)
+    print("train_full", grid, "loss", float(loss.item()), "tensors", len(d) - 2)
 
 
 def gen_fm(out):
@@ -516,6 +531,10 @@ def main():
         gen_metrics(a.out)
     if "loop" in todo:
         gen_loop(a.out)
+    if "train_grids" in todo:
+        gen_train_full(a.out, grid="cr120")
+    if "loop_grids" in todo:
+        gen_loop(a.out, grids_only=True)
 
 
 if __name__ == "__main__":
