@@ -73,7 +73,13 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvArgs a, cons
     if (oz < a.Zo && oy < a.Yo && ox < a.Xo) off = ((b * a.Zo + oz) * a.Yo + oy) * a.Xo + ox;
     hbase = ((z * HY + y) * HX + x) * S;
   }
-  const int t0 = grp * 27 / NG, t1 = (grp + 1) * 27 / NG;
+  // Specialised variant (TM = 64: one tap group per wave): the weights are wave-uniform, so they are read
+  // straight from global memory with scalar loads (s_load -> SGPR operands of the FMAs) instead of as
+  // broadcast LDS vectors -- the LDS pipe then only carries the A reads (it was the limiter: 4 weight reads
+  // per 16 FMAs).
+  constexpr bool WS = SPEC && ((BZ * BY * BX + 31) / 32) * 32 % 64 == 0;
+  const int grp_u = WS ? __builtin_amdgcn_readfirstlane(grp) : grp;
+  const int t0 = grp_u * 27 / NG, t1 = (grp_u + 1) * 27 / NG;
 
   float acc[NCO];
 #pragma unroll
@@ -86,7 +92,8 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvArgs a, cons
     if (ch < a.nch0) { src = a.src0; Cs = a.C0; c0 = ch * a_CK; cg0 = c0; }
     else { src = a.src1; Cs = a.C1; c0 = (ch - a.nch0) * a_CK; cg0 = a.C0 + c0; }
     __syncthreads();
-    for (int i = tid; i < 27 * a_CK * NCO; i += 256) W[i] = wsm[(size_t)ch * 27 * a_CK * NCO + i];
+    if constexpr (!WS)
+      for (int i = tid; i < 27 * a_CK * NCO; i += 256) W[i] = wsm[(size_t)ch * 27 * a_CK * NCO + i];
     for (int i = tid; i < HV * K4; i += 256) {
       const int hv = i / K4, q = i - hv * K4;
       const int hp = hvtab_at(hv);
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvArgs a, cons
     for (int t = t0; t < t1; ++t) {
       const int dz = t / 9, rem = t - dz * 9, dy = rem / 3, dx = rem - dy * 3;
       const float *ap = A + hbase + ((dz * HY + dy) * HX + dx) * S;
-      const float *wp = W + (size_t)t * a_CK * NCO;
+      const float *wp = WS ? wsm + ((size_t)ch * 27 + t) * a_CK * NCO : W + (size_t)t * a_CK * NCO;
       for (int q = 0; q < K4; ++q) {
         const f32x4 av = *reinterpret_cast<const f32x4 *>(ap + 4 * q);
 #pragma unroll

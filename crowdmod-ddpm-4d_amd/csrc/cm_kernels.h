@@ -85,6 +85,14 @@ bool conv_smalln_ok(const ConvArgs &a, int MB);
 size_t conv_smalln_lds(const ConvArgs &a, int MB);
 hipError_t launch_conv_smalln(const ConvArgs &a, int MB, const float *wsm, hipStream_t st);
 
+// The UNet's first conv (cm_conv_io.hip): C <= 8 input channels read from the [..][C0] input tensor, whole
+// weight set of a 32-channel output tile in registers, waves split the voxels of a (bz x by x full-X) tile.
+// wpk: [Co/32][27 * cin / 2][64 lanes]; a.bx == a.Xo, a.ntx == 1.
+bool conv_first_ok(const ConvArgs &a, int cin);
+int conv_first_blocks(const ConvArgs &a);    // 32-row accumulator blocks (= statistics slots) per tile
+size_t conv_first_lds(const ConvArgs &a, int cin);
+hipError_t launch_conv_first(const ConvArgs &a, int cin, const float *wpk, hipStream_t st);
+
 // ---- small kernels --------------------------------------------------------
 // Per-(sample, slice, channel) mean and M2 of a channels-last tensor.
 //   part [B][nslice][C][2]

@@ -103,6 +103,9 @@ struct Op {
   std::string skip_w, skip_b;
   float *d_s2w = nullptr, *d_bias_fused = nullptr;
   bool skip_if_fused = false;  // this op is the stand-alone skip conv that a later op absorbs
+  bool first_k = false;     // the UNet's first conv on its dedicated kernel (cm_conv_io.hip)
+  int first_cin = 4;        //   input channels it contracts per tap: 4 (C <= 4) or 8
+  float *d_wfirst = nullptr;
   bool small_n = false;     // <= 8 output channels: vector-ALU kernel (cm_conv_small.hip)
   float *d_wsmall = nullptr;
   int small_nco = 4;
@@ -426,6 +429,33 @@ const TunedTile *find_tuned(const cm::ConvArgs &a, int NB /* 0: any */) {
 // unsharded batch (SURVEY.md section 8e asks for bit-identical shards).
 constexpr int TUNE_BATCH = 64;
 
+// First conv (cm_conv_io.hip): tiles are bz x by planes of FULL x-rows; op.MB = 32-row blocks per tile
+// (= statistics slots per tile).  Score: fill of the last block, balance over the 4 waves, halo overhead,
+// enough tiles for the chip at the reference batch.
+void pick_tile_first(Op &op) {
+  cm::ConvArgs &a = op.ca;
+  double best = -1;
+  int bbz = 1, bby = 1;
+  a.bs = 1; a.bx = a.Xo;
+  for (int bz = 1; bz <= a.Zo; ++bz)
+    for (int by = 1; by <= a.Yo; ++by) {
+      if (a.Zo % bz || a.Yo % by) continue;
+      a.bz = bz; a.by = by;
+      const int nbox = bz * by * a.Xo, nblk = (nbox + 31) / 32;
+      if (nblk > 16 || cm::conv_first_lds(a, op.first_cin) > 48 * 1024) continue;
+      const double tiles = (double)(a.Zo / bz) * (a.Yo / by) * TUNE_BATCH;
+      if ((a.Zo / bz) * (a.Yo / by) * nblk > MAX_SLOTS) continue;
+      const double eff = (double)nbox / (32.0 * nblk);
+      const double bal = (double)nblk / (4.0 * ((nblk + 3) / 4));
+      const double halo = (double)nbox / ((bz + 2.0) * (by + 2.0) * (a.Xo + 2.0));
+      const double score = eff * bal * (0.5 + 0.5 * halo) * std::min(1.0, tiles / 512.0);
+      if (score > best) { best = score; bbz = bz; bby = by; }
+    }
+  a.bz = bbz; a.by = bby;
+  a.ntz = a.Zo / bbz; a.nty = a.Yo / bby; a.ntx = 1;
+  op.MB = cm::conv_first_blocks(a);
+}
+
 void pick_tile(Op &op, int B) {
   cm::ConvArgs &a = op.ca;
   const int NB = op.NB;
@@ -578,6 +608,22 @@ int add_conv(cm_model *m, const ConvSpec &s) {
             if (cig < Ci_ref) ws[(((size_t)ch * 27 + t) * a.CK + ci) * nco + co] = wi[((size_t)co * Ci_ref + cig) * 27 + t];
           }
     if (upload(m, ws, &op.d_wsmall)) return 1;
+  }
+  // the UNet's first conv (C <= 8 data channels -> base): dedicated kernel, whole weight set in registers
+  if (s.s0 == m->x8_act && s.ntaps == 27 && s.stride == 1 && !s.ups && !s.gn && !s.temb && !s.resid && !s.s1 &&
+      s.Co % 32 == 0 && Ci_ref <= 8 && !getenv("CM_NO_FIRSTK")) {
+    op.first_k = true;
+    op.first_cin = Ci_ref <= 4 ? 4 : 8;
+    const int cin = op.first_cin, NS = 27 * cin / 2, hc = cin / 2, ntn = s.Co / 32;
+    std::vector<float> wp((size_t)ntn * NS * 64, 0.f);
+    for (int nt = 0; nt < ntn; ++nt)
+      for (int t = 0; t < 27; ++t)
+        for (int pp = 0; pp < hc; ++pp)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int co = nt * 32 + (lane & 31), ci = hc * (lane >> 5) + pp;   // MFMA (t, pp) contracts k = {hc*hh + pp}
+            if (ci < Ci_ref) wp[((size_t)nt * NS + t * hc + pp) * 64 + lane] = wi[((size_t)co * Ci_ref + ci) * 27 + t];
+          }
+    if (upload(m, wp, &op.d_wfirst)) return 1;
   }
   float *dw = nullptr, *db = nullptr;
   if (upload(m, wf, &dw)) return 1;
@@ -872,6 +918,11 @@ int build_time_table(cm_model *m) {
 // One convolution op of the plan for the `B` samples starting at `b0` (see run_ops).
 int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   if (op.skip_if_fused && !m->train_fwd) return 0;  // absorbed by the block's conv_2 (inference plan)
+  if (op.tuned_B < 0 && op.first_k) {
+    pick_tile_first(op);
+    op.tuned_B = B;
+    if (!cm::conv_first_ok(op.ca, op.first_cin)) return fail("first-conv tile does not fit");
+  }
   if (op.tuned_B < 0) {
     pick_tile(op, TUNE_BATCH);
     op.tuned_B = B;
@@ -943,6 +994,8 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     cb.stat_cnt = op.stat_act->cnt + (size_t)b0 * cb.nslots;
     op.stat_act->nslots = cb.nslots;
     CM_HIP(cm::launch_ksplit_combine(cb, st));
+  } else if (op.first_k) {
+    CM_HIP(cm::launch_conv_first(ca, op.first_cin, op.d_wfirst, st));
   } else if (op.small_n) {
     CM_HIP(cm::launch_conv_smalln(ca, op.MB, op.d_wsmall, st));
   } else {
@@ -1753,7 +1806,7 @@ int cm_debug_conv_info(const cm_model *m, int32_t index, char *buf, int64_t capa
   const cm::ConvArgs &a = op.ca;
   snprintf(buf, (size_t)capacity, "conv %s %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d", op.label.c_str(), a.ntaps, a.stride, a.par,
            a.C0 + a.C1, a.Co, a.Zo, a.Yo, a.Xo, op.NB, op.MB, a.bz, a.by, a.bx, op.ks,
-           (op.small_n ? 1 : 0) | (op.stat_act ? 4 : 0) | (op.skip_if_fused ? 8 : 0) | (a.CK == 32 ? 16 : 0));
+           (op.small_n ? 1 : 0) | (op.first_k ? 2 : 0) | (op.stat_act ? 4 : 0) | (op.skip_if_fused ? 8 : 0) | (a.CK == 32 ? 16 : 0));
   return 0;
 }
 
@@ -1764,7 +1817,7 @@ int cm_debug_time_conv(cm_model *m, int32_t index, int32_t MB, int32_t bz, int32
   if (check_ready(m, B)) return 1;
   if (!us || index < 0 || index >= (int)m->ops.size() || iters < 1) return fail("bad argument");
   Op &op = m->ops[index];
-  if (op.kind != OP_CONV) return fail("op %d is not a tunable convolution", index);
+  if (op.kind != OP_CONV || (op.first_k && MB > 0)) return fail("op %d is not a tunable convolution", index);
   if (op.tuned_B < 0) return fail("run a forward first");
   DevGuard g(m->device);
   hipStream_t st = m->stream;
