@@ -44,8 +44,10 @@ __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_r
 #ifndef CM_SPEC_OCC
 #define CM_SPEC_OCC 2
 #endif
-template <int MB, int NB, int FAST, int BZ = 0, int BY = 0, int BX = 0, int STR = 1>
-__global__ __launch_bounds__(256, (BZ != 0 && MB * NB <= 4 ? CM_SPEC_OCC : 2)) void conv_mfma_kernel(const ConvArgs a) {
+// OCC != 0: requested waves per SIMD (= workgroups per CU); 3 for the MB = 3 full-resolution tiles, whose
+// smaller accumulator set fits 168 VGPRs.
+template <int MB, int NB, int FAST, int BZ = 0, int BY = 0, int BX = 0, int STR = 1, int OCC = 0>
+__global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPEC_OCC : 2))) void conv_mfma_kernel(const ConvArgs a) {
   constexpr bool SPEC = BZ != 0;
   constexpr bool SPAR = SPEC && (FAST % 100) == 8;   // specialised parity form: 2 taps per dimension
   constexpr int STD = SPAR ? 2 : 3;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256, (BZ != 0 && MB * NB <= 4 ? CM_SPEC_OCC : 2)) v
   // Row mode: a thread owns one or two whole x-rows of the halo box (row = hz * HY + hy), so the
   // coordinate decode and the bounds of z / y happen once per row instead of once per voxel.
   const int HR = HZ * HY, RJ = (HR + 31) >> 5;
-  const bool rowmode = fstage && a_ups == 0 && RJ * HX <= NVM && (SPEC || !(a.dbg & 512));
+  const bool rowmode = fstage && a_ups == 0 && RJ <= 2 && RJ * HX <= NVM && (SPEC || !(a.dbg & 512));
   // slot k of a thread: (row lane j, x) in row mode, voxel v0 + 32 k otherwise
   auto slot_j = [&](int k) { return RJ == 2 ? k / (NVM / 2) : 0; };
   auto slot_x = [&](int k) { return RJ == 2 ? k % (NVM / 2) : k; };
@@ -724,6 +726,14 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
     if (a.s2w) CM_LAUNCH_T((conv_mfma_kernel<m, n, 127, z, y, x>), m, n, 127)      \
     CM_LAUNCH_T((conv_mfma_kernel<m, n, 27, z, y, x>), m, n, 27)                   \
   }
+#define CM_SPEC3(m, n, z, y, x)                                                    \
+  if (specok && MB == m && NB == n && a.bz == z && a.by == y && a.bx == x) {       \
+    if (a.s2w) CM_LAUNCH_T((conv_mfma_kernel<m, n, 127, z, y, x, 1, 3>), m, n, 127) \
+    CM_LAUNCH_T((conv_mfma_kernel<m, n, 27, z, y, x, 1, 3>), m, n, 27)             \
+  }
+  CM_SPEC3(3, 1, 8, 6, 2)  // full resolution, three workgroups per CU (128 VGPRs): -7 % vs MB4 8x4x4 at 2 per CU
+  CM_SPEC3(3, 1, 8, 4, 3)  //   (8x3x4, 4x4x6, 4x6x4, 8x2x6 measured slower: 118 / 136 / 111 / 134 us vs 108 on the 32->32 layer)
+#undef CM_SPEC3
   CM_SPEC(4, 1, 8, 4, 4)   // ATC / 2x grid full resolution
   CM_SPEC(2, 2, 2, 3, 9)   // ATC half and quarter resolution
   CM_SPEC(2, 2, 2, 6, 5)
