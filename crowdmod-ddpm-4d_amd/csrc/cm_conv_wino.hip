@@ -1,0 +1,276 @@
+// 3x3x3 stride-1 convolution with a Winograd F(2x2, 3x3) transform over the two in-plane axes (Y, X) and
+// direct summation over the frame axis Z -- the full-resolution nn.Conv3d layers of the reference UNet
+// (/root/reference/models/backbones/layers.py:32,43; the layers that are 46 % of a denoise step).
+//
+// Why: on gfx950 the exact-fp32 matrix instruction runs at the fp32 VECTOR rate and does not overlap other
+// vector work on its SIMD (profiles/round1_notes.md), so a direct implicit GEMM cannot beat
+// 27 * Ci * Co MACs per voxel plus its staging / epilogue instructions.  F(2x2, 3x3) needs 16 multiplies
+// per 2x2 outputs and z tap instead of 36: 12 MACs per voxel and (ci, co) pair instead of 27 -- 2.25x fewer
+// matrix instructions for the same fp32 result up to rounding (measured error vs the reference: see the
+// parity tests; the transforms only add / subtract and scale weights by 1/2, 1/4).
+//
+// One 256-thread workgroup = one sample's BZ x BY x BX output box (BZ * (BY/2) * (BX/2) = 32 patch rows):
+//   * per 16-channel chunk every thread item (input plane zi, patch, channel quad) loads its 4x4 input
+//     patch straight from global memory (GroupNorm affine + SiLU + Dropout3d multiplier applied on the fly,
+//     zero padding as a mask), applies B^T d B in registers and writes the 16 frequency components to LDS as
+//     U[xi][zi * NP + patch][ci]: the 32 rows of a component are CONSECUTIVE, so the A fragments are
+//     conflict-free ds_read_b128 and the z tap is a plain row offset;
+//   * wave w owns the frequency row xi_y = w (4 components xi_x): 4 accumulator blocks 32 rows x 32 channels,
+//     K = 3 z taps x 16 channels per chunk; weights (G g G^T, packed on the host per wave in consumption
+//     order) stream global -> VGPR through a two-group register ring;  no cross-wave K reduction;
+//   * output transform: A^T along x in registers (4 blocks -> 2), exchange through LDS, A^T along y: wave w
+//     ends with the output sub-block (a, b) = (w >> 1, w & 1) of every patch -- 32 voxels x 32 channels -- and
+//     runs the same epilogue as the direct kernel (bias, time-embedding row, residual, channels-last store,
+//     GroupNorm statistics of the block in the slot format of gn_finalize).
+#include "cm_kernels.h"
+
+namespace cm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+template <int BZ, int BY, int BX, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
+  constexpr int PY = BY / 2, PX = BX / 2, NP = PY * PX;
+  static_assert(BZ * NP == 32, "one 32-row accumulator block per frequency component");
+  constexpr int HZ = BZ + 2, UR = HZ * NP;      // input planes, rows per component in LDS
+  constexpr int CS = 16, S = CS + 4;            // channel chunk, LDS row stride (conflict-free b128 for consecutive rows)
+  constexpr int NITEMS = HZ * NP * (CS / 4);    // staging items: (plane, patch, channel quad)
+  static_assert(NITEMS <= 256, "one staging item per thread");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int *outoff = reinterpret_cast<int *>(lds);   // [4 sub-blocks (a, b)][32 rows] output voxel index or -1
+  float *U = lds + 128;                         // [16][UR][S]; later the exchange buffer [4 waves][2][16][64]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  int tile = blockIdx.x;
+  if (!(gridDim.x & 7) && !(a.dbg & 4096)) tile = (tile & 7) * (int)(gridDim.x >> 3) + (tile >> 3);  // XCD-aware order (cm_conv.hip)
+  const int tx = tile % a.ntx; tile /= a.ntx;
+  const int ty = tile % a.nty; tile /= a.nty;
+  const int tz = tile % a.ntz;
+  const int b0 = tile / a.ntz;
+  const int nt = blockIdx.y;
+  const int z0 = tz * BZ, y0 = ty * BY, x0 = tx * BX;
+  const int bs = b0 < a.B ? b0 : 0;             // (grid is exact; kept for safety)
+
+  if (tid < 128) {
+    const int ab = tid >> 5, row = tid & 31;
+    const int zr = row / NP, pr = row % NP, py = pr / PX, px = pr % PX;
+    const int oz = z0 + zr, oy = y0 + 2 * py + (ab >> 1), ox = x0 + 2 * px + (ab & 1);
+    outoff[tid] = (b0 < a.B && oz < a.Zo && oy < a.Yo && ox < a.Xo) ? ((b0 * a.Zo + oz) * a.Yo + oy) * a.Xo + ox : -1;
+  }
+  // ---- this thread's staging item: source voxel offsets of its 4x4 patch, resolved once ---------------
+  const bool stager = tid < NITEMS;
+  const int it = stager ? tid : 0;
+  const int quad = it & 3, patch = (it >> 2) % NP, zi = it / (4 * NP);
+  int soff[16];
+  unsigned okmask = 0;
+  {
+    const int py = patch / PX, px = patch % PX;
+    const int cz = z0 - 1 + zi;
+    const bool zok = stager && b0 < a.B && cz >= 0 && cz < a.Zs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cy = y0 + 2 * py - 1 + i, cx = x0 + 2 * px - 1 + j;
+        const bool ok = zok && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs;
+        soff[i * 4 + j] = ok ? ((bs * a.Zs + cz) * a.Ys + cy) * a.Xs + cx : 0;
+        okmask |= (ok ? 1u : 0u) << (i * 4 + j);
+      }
+  }
+  float *const uw = U + (size_t)(zi * NP + patch) * S + 4 * quad;   // + xi * UR * S per component
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[x][i] = 0.f;
+
+  const int n0 = a.C0 >> 4, nchunks = n0 + (a.C1 >> 4);
+  const int Ctot = a.C0 + a.C1;
+  // packed weights: [n tile][chunk][wave = xi_y][group g = dz * 2 + k8][xi_x][lane] float4
+  const f32x4 *wbase = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * nchunks * (4 * 24 * 64) + wave * (24 * 64) + lane;
+  f32x4 bq[2][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) bq[0][x] = wbase[x * 64];
+
+  const float *arow = U + (size_t)(wave * 4) * UR * S + (size_t)r * S + 4 * hh;   // component xi_y = wave, xi_x = 0, tap 0
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float *src;
+    int Cs, c0, cg0;
+    if (ch < n0) { src = a.src0; Cs = a.C0; c0 = ch * CS; cg0 = c0; }
+    else { src = a.src1; Cs = a.C1; c0 = (ch - n0) * CS; cg0 = a.C0 + c0; }
+    // ---- stage + input transform ---------------------------------------------------------------------
+    f32x4 d[16];
+    const float *sp = src + c0 + 4 * quad;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = *reinterpret_cast<const f32x4 *>(sp + (size_t)soff[k] * Cs);
+    f32x4 sc1 = {1.f, 1.f, 1.f, 1.f}, sh1 = {0.f, 0.f, 0.f, 0.f}, pm1 = {1.f, 1.f, 1.f, 1.f};
+    if (a.gn) {
+      const float *g = a.gn + (size_t)bs * 2 * Ctot + cg0 + 4 * quad;
+      sc1 = *reinterpret_cast<const f32x4 *>(g);
+      sh1 = *reinterpret_cast<const f32x4 *>(g + Ctot);
+    }
+    if (a.pm) pm1 = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)bs * a.pm_stride + cg0 + 4 * quad);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      f32x4 w = d[k];
+      if (a.gn) {
+        w = w * sc1 + sh1;
+        if (a.silu) { w[0] = silu_w(w[0]); w[1] = silu_w(w[1]); w[2] = silu_w(w[2]); w[3] = silu_w(w[3]); }
+      }
+      if (a.pm) w = w * pm1;
+      if (!((okmask >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding of the ACTIVATED tensor
+      d[k] = w;
+    }
+    // B^T d B: rows of B^T = (1,0,-1,0), (0,1,1,0), (0,-1,1,0), (0,1,0,-1); first along x (index j), then y (i)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 e0 = d[i * 4 + 0], e1 = d[i * 4 + 1], e2 = d[i * 4 + 2], e3 = d[i * 4 + 3];
+      d[i * 4 + 0] = e0 - e2; d[i * 4 + 1] = e1 + e2; d[i * 4 + 2] = e2 - e1; d[i * 4 + 3] = e1 - e3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j], e3 = d[3 * 4 + j];
+      d[0 * 4 + j] = e0 - e2; d[1 * 4 + j] = e1 + e2; d[2 * 4 + j] = e2 - e1; d[3 * 4 + j] = e1 - e3;
+    }
+    __syncthreads();                        // previous chunk's fragments have been read
+    if (stager) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4 *>(uw + (size_t)k * UR * S) = d[k];   // component xi = i * 4 + j = k
+    }
+    __syncthreads();
+    // ---- matrix phase: 6 groups (z tap, 8-channel half) x 4 components ------------------------------
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      const int dz = g >> 1, k8 = g & 1;
+      // refill the other ring slot with the next group (possibly the next chunk's first)
+      {
+        const bool more = g < 5 || ch + 1 < nchunks;
+        const f32x4 *wn = wbase + (size_t)(g < 5 ? ch : ch + 1) * (4 * 24 * 64) + (size_t)(g < 5 ? g + 1 : 0) * (4 * 64);
+        if (more) {
+#pragma unroll
+          for (int x = 0; x < 4; ++x) bq[(g + 1) & 1][x] = wn[x * 64];
+        }
+      }
+      f32x4 af[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) af[x] = *reinterpret_cast<const f32x4 *>(arow + (size_t)x * UR * S + (size_t)dz * NP * S + 8 * k8);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x][jj], bq[g & 1][x][jj], acc[x], 0, 0, 0);
+    }
+  }
+
+  // ---- output transform: A^T = (1,1,1,0), (0,1,-1,-1) along x in registers, along y through LDS -----------
+  f32x16 t0 = acc[0] + acc[1] + acc[2];
+  f32x16 t1 = acc[1] - acc[2] - acc[3];
+  __syncthreads();                          // U is dead: reuse as the exchange buffer
+  float *xb = U + (size_t)(wave * 2) * 16 * 64 + lane;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) { xb[reg * 64] = t0[reg]; xb[(16 + reg) * 64] = t1[reg]; }
+  __syncthreads();
+  const int oa = wave >> 1, ob = wave & 1;   // this wave's output sub-block
+  f32x16 v;
+  {
+    const float *p0 = U + (size_t)((0 * 2 + ob) * 16) * 64 + lane, *p1 = U + (size_t)((1 * 2 + ob) * 16) * 64 + lane;
+    const float *p2 = U + (size_t)((2 * 2 + ob) * 16) * 64 + lane, *p3 = U + (size_t)((3 * 2 + ob) * 16) * 64 + lane;
+    if (oa == 0) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) v[reg] = (p0[reg * 64] + p1[reg * 64]) + p2[reg * 64];
+    } else {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) v[reg] = (p1[reg * 64] - p2[reg * 64]) - p3[reg * 64];
+    }
+  }
+  // ---- epilogue of the 32-voxel x 32-channel sub-block (same arithmetic as the direct kernel's) ------------
+  const int n = nt * 32 + r;
+  const bool nok = n < a.Co;
+  const int nc = nok ? n : 0;
+  const float bias = a.bias[nc];
+  int offs[16];
+  float rs[16];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) offs[reg] = outoff[wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) rs[reg] = v[reg] + bias;
+  if (a.temb) {
+    const float tv = a.temb[(size_t)a.tidx[bs] * a.temb_stride + nc];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) rs[reg] += tv;
+  }
+  if (a.resid) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int oc = offs[reg] >= 0 ? offs[reg] : 0;
+      rs[reg] += a.resid[(size_t)oc * a.res_cs + nc];
+    }
+  }
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg)
+    if (nok && offs[reg] >= 0) a.out[(size_t)offs[reg] * a.out_cs + n] = rs[reg];
+  if (a.stat_part) {
+    float s1 = 0.f, cnt = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg)
+      if (offs[reg] >= 0) { s1 += rs[reg]; cnt += 1.f; }
+    s1 += __shfl_xor(s1, 32);
+    cnt += __shfl_xor(cnt, 32);
+    const float mean = cnt > 0.f ? s1 / cnt : 0.f;
+    float q = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg)
+      if (offs[reg] >= 0) { const float dd = rs[reg] - mean; q += dd * dd; }
+    q += __shfl_xor(q, 32);
+    const int slot = (((tz * a.nty + ty) * a.ntx) + tx) * 4 + wave;
+    if (hh == 0 && nok && b0 < a.B) {
+      float *sp2 = a.stat_part + (((size_t)b0 * a.stat_ns + slot) * a.stat_C + n) * 2;
+      sp2[0] = mean;
+      sp2[1] = q;
+    }
+    if (lane == 0 && n == 0 && b0 < a.B) a.stat_cnt[(size_t)b0 * a.stat_ns + slot] = cnt;
+  }
+}
+
+// tile shapes with BZ * (BY/2) * (BX/2) == 32
+bool conv_wino_tile_ok(int bz, int by, int bx) {
+  return (bz == 8 && by == 4 && bx == 4) || (bz == 4 && by == 4 && bx == 8) || (bz == 4 && by == 8 && bx == 4) ||
+         (bz == 2 && by == 8 && bx == 8);
+}
+
+size_t conv_wino_lds(int bz, int by, int bx) {
+  const size_t ur = (size_t)(bz + 2) * (by / 2) * (bx / 2);
+  const size_t u = 16 * ur * 20, x = 4 * 2 * 16 * 64;
+  return (128 + (u > x ? u : x)) * sizeof(float);
+}
+
+bool conv_wino_ok(const ConvArgs &a) {
+  return a.ntaps == 27 && a.td == 3 && a.stride == 1 && !a.par && !a.ups && a.ks <= 1 && a.bs == 1 && !a.s2w &&
+         a.C0 % 16 == 0 && a.C1 % 16 == 0 && conv_wino_tile_ok(a.bz, a.by, a.bx) && a.Zo % a.bz == 0 && a.Yo % a.by == 0 &&
+         a.Xo % a.bx == 0 && a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo;
+}
+
+hipError_t launch_conv_wino(const ConvArgs &a_in, hipStream_t st) {
+  ConvArgs a = a_in;
+  a.dbg = conv_dbg_flags();
+  if (!conv_wino_ok(a)) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)(a.B * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + 31) / 32));
+  const size_t lds = conv_wino_lds(a.bz, a.by, a.bx);
+#define CM_WINO(z, y, x)                                                                            \
+  if (a.bz == z && a.by == y && a.bx == x) {                                                        \
+    hipLaunchKernelGGL((conv_wino_kernel<z, y, x, 2>), grid, dim3(256), lds, st, a);                \
+    return hipGetLastError();                                                                       \
+  }
+  CM_WINO(8, 4, 4) CM_WINO(4, 4, 8) CM_WINO(4, 8, 4) CM_WINO(2, 8, 8)
+#undef CM_WINO
+  return hipErrorInvalidValue;
+}
+
+}  // namespace cm

@@ -93,6 +93,14 @@ int conv_first_blocks(const ConvArgs &a);    // 32-row accumulator blocks (= sta
 size_t conv_first_lds(const ConvArgs &a, int cin);
 hipError_t launch_conv_first(const ConvArgs &a, int cin, const float *wpk, hipStream_t st);
 
+// Winograd F(2x2, 3x3) over (Y, X), direct over Z (cm_conv_wino.hip): stride-1 3x3x3 convs whose output box
+// tiles as bz x by x bx with bz * (by/2) * (bx/2) == 32.  a.wfrag: [Co/32][Ci/16][4 = xi_y][24 = (dz*2 + k8)*4 + xi_x]
+// [64 lanes][4] transformed weights; statistics slots per tile: 4 (the (a, b) sub-blocks).
+bool conv_wino_tile_ok(int bz, int by, int bx);
+bool conv_wino_ok(const ConvArgs &a);
+size_t conv_wino_lds(int bz, int by, int bx);
+hipError_t launch_conv_wino(const ConvArgs &a, hipStream_t st);
+
 // ---- small kernels --------------------------------------------------------
 // Per-(sample, slice, channel) mean and M2 of a channels-last tensor.
 //   part [B][nslice][C][2]
@@ -230,7 +238,7 @@ hipError_t launch_time_bwd(const TimeBwdArgs &a, hipStream_t st);
 hipError_t launch_adam(float *p, const float *g, float *m, float *v, long long n, float lr, float b1, float b2,
                        float eps, float wd, int step, hipStream_t st);
 hipError_t launch_gather_pack(const float *W, const int *idx, int nk, float *packed, long long n, hipStream_t st);
-struct PackJob { float *dst; const int *idx; long long start; int nk; int pad; };
+struct PackJob { float *dst; const int *idx; const float *coef; long long start; int nk; int pad; };   // coef: optional weights of the nk terms
 hipError_t launch_gather_pack_jobs(const float *W, const PackJob *jobs, int njobs, long long total, hipStream_t st);
 
 }  // namespace cm

@@ -103,6 +103,8 @@ struct Op {
   std::string skip_w, skip_b;
   float *d_s2w = nullptr, *d_bias_fused = nullptr;
   bool skip_if_fused = false;  // this op is the stand-alone skip conv that a later op absorbs
+  bool wino = false;        // Winograd F(2x2,3x3) kernel (cm_conv_wino.hip): full-resolution stride-1 3x3x3 layers
+  float *d_wwino = nullptr;
   bool first_k = false;     // the UNet's first conv on its dedicated kernel (cm_conv_io.hip)
   int first_cin = 4;        //   input channels it contracts per tap: 4 (C <= 4) or 8
   float *d_wfirst = nullptr;
@@ -396,6 +398,38 @@ std::vector<float> pack_conv_weights(const float *W, int Co, int Ci, int ntaps, 
   return out;
 }
 
+// Winograd F(2x2, 3x3) weights over the in-plane taps (dy, dx), one 4x4 transform G g G^T per (co, ci, dz):
+//   G = (1,0,0), (1/2,1/2,1/2), (1/2,-1/2,1/2), (0,0,1).
+// Layout (cm_conv_wino.hip): [n tile][16-channel chunk][xi_y][step = (dz*2 + k8)*4 + xi_x][lane][jj] with
+// lane = 32*hh + (co % 32), ci = chunk*16 + 8*k8 + 4*hh + jj.  `wi` is the internal tap order [Co][Ci][27].
+// With `ii` (global indices of the taps) the same walk emits, per packed element, the 9 (index, coefficient)
+// terms for the device-side re-pack after an optimizer step.
+void pack_wino(const std::vector<float> *wi, const std::vector<int> *ii, int Co, int Ci, int Ci_pad, std::vector<float> *out,
+               std::vector<int> *oidx, std::vector<float> *ocoef) {
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  const int ntn = (Co + 31) / 32, nch = Ci_pad / 16;
+  const size_t total = (size_t)ntn * nch * 4 * 24 * 64 * 4;
+  if (out) out->assign(total, 0.f);
+  if (oidx) { oidx->assign(total * 9, -1); ocoef->assign(total * 9, 0.f); }
+  for (int co = 0; co < Co; ++co)
+    for (int ci = 0; ci < Ci; ++ci)
+      for (int dz = 0; dz < 3; ++dz)
+        for (int xy = 0; xy < 4; ++xy)
+          for (int xx = 0; xx < 4; ++xx) {
+            const int nt = co / 32, r = co % 32, chunk = ci / 16, k8 = (ci % 16) / 8, hh = (ci % 8) / 4, jj = ci % 4;
+            const size_t o = ((((((size_t)nt * nch + chunk) * 4 + xy) * 24 + (dz * 2 + k8) * 4 + xx) * 64) + hh * 32 + r) * 4 + jj;
+            double acc = 0;
+            for (int dy = 0; dy < 3; ++dy)
+              for (int dx = 0; dx < 3; ++dx) {
+                const size_t t = ((size_t)co * Ci + ci) * 27 + (dz * 3 + dy) * 3 + dx;
+                const double c = G[xy][dy] * G[xx][dx];
+                if (wi) acc += c * (double)(*wi)[t];
+                if (oidx && c != 0.0) { (*oidx)[o * 9 + dy * 3 + dx] = (*ii)[t]; (*ocoef)[o * 9 + dy * 3 + dx] = (float)c; }
+              }
+            if (out) (*out)[o] = (float)acc;
+          }
+}
+
 int pick_ck(int C0, int C1) {
   for (int ck : {32, 16, 8})
     if (C0 % ck == 0 && C1 % ck == 0) return ck;
@@ -609,6 +643,19 @@ int add_conv(cm_model *m, const ConvSpec &s) {
           }
     if (upload(m, ws, &op.d_wsmall)) return 1;
   }
+  // full-resolution stride-1 3x3x3 layers: Winograd F(2x2,3x3) over (Y, X) -- 2.25x fewer matrix instructions
+  {
+    static const int wz[4][3] = {{8, 4, 4}, {4, 4, 8}, {4, 8, 4}, {2, 8, 8}};
+    bool tiles = false;
+    for (auto &t : wz) tiles = tiles || (s.out->Z % t[0] == 0 && s.out->Y % t[1] == 0 && s.out->X % t[2] == 0);
+    if (s.ntaps == 27 && s.stride == 1 && !s.ups && a.C0 % 16 == 0 && a.C1 % 16 == 0 && s.Co % 32 == 0 && s.Co == s.out->C &&
+        Ci_ref == Ci_pad && tiles && s.out->V() > 64 && !getenv("CM_NO_WINO")) {
+      op.wino = true;
+      std::vector<float> ww;
+      pack_wino(&wi, nullptr, s.Co, Ci_ref, Ci_pad, &ww, nullptr, nullptr);
+      if (upload(m, ww, &op.d_wwino)) return 1;
+    }
+  }
   // the UNet's first conv (C <= 8 data channels -> base): dedicated kernel, whole weight set in registers
   if (s.s0 == m->x8_act && s.ntaps == 27 && s.stride == 1 && !s.ups && !s.gn && !s.temb && !s.resid && !s.s1 &&
       s.Co % 32 == 0 && Ci_ref <= 8 && !getenv("CM_NO_FIRSTK")) {
@@ -657,7 +704,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     if (upload(m, zb, &op.d_zero_bias)) return 1;
   }
   // fuse the 1x1x1 skip conv when this conv runs on the 27-tap register-ring path without K split
-  if (s.skip0 && s.ntaps == 27 && !parity && a.CK == 32 && !op.small_n && s.stride == 1 &&
+  if (s.skip0 && s.ntaps == 27 && !parity && a.CK == 32 && !op.small_n && !op.wino && s.stride == 1 &&
       s.skip0->C % 32 == 0 && (!s.skip1 || s.skip1->C % 32 == 0) && !getenv("CM_NO_FUSE_SKIP")) {
     const Param &w2 = P(m, s.skip_w);
     const Param &b2 = P(m, s.skip_b);
@@ -918,6 +965,17 @@ int build_time_table(cm_model *m) {
 // One convolution op of the plan for the `B` samples starting at `b0` (see run_ops).
 int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   if (op.skip_if_fused && !m->train_fwd) return 0;  // absorbed by the block's conv_2 (inference plan)
+  if (op.tuned_B < 0 && op.wino) {
+    static const int wz[4][3] = {{8, 4, 4}, {4, 4, 8}, {4, 8, 4}, {2, 8, 8}};
+    cm::ConvArgs &a = op.ca;
+    a.bs = 1;
+    for (auto &t : wz)
+      if (a.Zo % t[0] == 0 && a.Yo % t[1] == 0 && a.Xo % t[2] == 0) { a.bz = t[0]; a.by = t[1]; a.bx = t[2]; break; }
+    a.ntz = a.Zo / a.bz; a.nty = a.Yo / a.by; a.ntx = a.Xo / a.bx;
+    op.MB = 4;                       // statistics slots per tile: the four (a, b) output sub-blocks
+    op.tuned_B = B;
+    if (!cm::conv_wino_ok(a)) return fail("Winograd tile does not fit %s", op.label.c_str());
+  }
   if (op.tuned_B < 0 && op.first_k) {
     pick_tile_first(op);
     op.tuned_B = B;
@@ -994,6 +1052,9 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     cb.stat_cnt = op.stat_act->cnt + (size_t)b0 * cb.nslots;
     op.stat_act->nslots = cb.nslots;
     CM_HIP(cm::launch_ksplit_combine(cb, st));
+  } else if (op.wino) {
+    ca.wfrag = op.d_wwino;
+    CM_HIP(cm::launch_conv_wino(ca, st));
   } else if (op.first_k) {
     CM_HIP(cm::launch_conv_first(ca, op.first_cin, op.d_wfirst, st));
   } else if (op.small_n) {
@@ -1817,7 +1878,7 @@ int cm_debug_time_conv(cm_model *m, int32_t index, int32_t MB, int32_t bz, int32
   if (check_ready(m, B)) return 1;
   if (!us || index < 0 || index >= (int)m->ops.size() || iters < 1) return fail("bad argument");
   Op &op = m->ops[index];
-  if (op.kind != OP_CONV || (op.first_k && MB > 0)) return fail("op %d is not a tunable convolution", index);
+  if (op.kind != OP_CONV || ((op.first_k || op.wino) && MB > 0)) return fail("op %d is not a tunable convolution", index);
   if (op.tuned_B < 0) return fail("run a forward first");
   DevGuard g(m->device);
   hipStream_t st = m->stream;

@@ -738,7 +738,7 @@ __global__ void gather_pack_jobs_kernel(const float *__restrict__ W, const PackJ
   float s = 0.f;
   for (int k = 0; k < jb.nk; ++k) {
     const int j = jb.idx[e * jb.nk + k];
-    if (j >= 0) s += W[j];
+    if (j >= 0) s += jb.coef ? jb.coef[e * jb.nk + k] * W[j] : W[j];   // Winograd weights: G g G^T is a weighted sum of 9 taps
   }
   jb.dst[e] = s;
 }
