@@ -169,6 +169,28 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
     }
   }
 
+  // ---- fused 1x1x1 skip convolution (ResnetBlock.match_input, layers.py:46,74; inference plan): issue the loads
+  // of its operands now -- the RAW block input at this wave's 32 output voxels and the packed 1x1 weights -- so
+  // that their latency hides behind the output transform; the MFMAs run on the finished sub-block below.
+  constexpr int SKB = 3;                     // 32-channel chunks per batch (full-resolution skips have 2 or 3)
+  const int n2a = a.s2C0 >> 5, n2 = a.s2w ? (a.s2C0 + a.s2C1) >> 5 : 0;
+  f32x4 sa[SKB][4], sw[SKB][4];
+  int svox = 0;
+  if (n2 > 0) {                              // wave-uniform
+    const int o = outoff[wave * 32 + r];     // A operand: lane = (row r, k half hh)
+    svox = o >= 0 ? o : 0;
+    const f32x4 *w2 = reinterpret_cast<const f32x4 *>(a.s2w) + (size_t)nt * n2 * 4 * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < SKB; ++u) {
+      const int c2 = u < n2 ? u : n2 - 1;
+      const float *s2 = c2 < n2a ? a.s2src0 + (size_t)svox * a.s2C0 + c2 * 32 : a.s2src1 + (size_t)svox * a.s2C1 + (c2 - n2a) * 32;
+#pragma unroll
+      for (int k8 = 0; k8 < 4; ++k8) {
+        sa[u][k8] = *reinterpret_cast<const f32x4 *>(s2 + 8 * k8 + 4 * hh);
+        sw[u][k8] = w2[(size_t)(c2 * 4 + k8) * 64];
+      }
+    }
+  }
   // ---- output transform: A^T = (1,1,1,0), (0,1,-1,-1) along x in registers, along y through LDS -----------
   f32x16 t0 = acc[0] + acc[1] + acc[2];
   f32x16 t1 = acc[1] - acc[2] - acc[3];
@@ -188,6 +210,31 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
     } else {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) v[reg] = (p1[reg * 64] - p2[reg * 64]) - p3[reg * 64];
+    }
+  }
+  if (n2 > 0) {
+    for (int c0s = 0; c0s < n2; c0s += SKB) {
+      if (c0s > 0) {                          // further batches (more than SKB chunks): loaded here, latency exposed
+        const f32x4 *w2 = reinterpret_cast<const f32x4 *>(a.s2w) + (size_t)nt * n2 * 4 * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < SKB; ++u) {
+          const int c2 = c0s + u < n2 ? c0s + u : n2 - 1;
+          const float *s2 = c2 < n2a ? a.s2src0 + (size_t)svox * a.s2C0 + c2 * 32 : a.s2src1 + (size_t)svox * a.s2C1 + (c2 - n2a) * 32;
+#pragma unroll
+          for (int k8 = 0; k8 < 4; ++k8) {
+            sa[u][k8] = *reinterpret_cast<const f32x4 *>(s2 + 8 * k8 + 4 * hh);
+            sw[u][k8] = w2[(size_t)(c2 * 4 + k8) * 64];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < SKB; ++u)
+        if (c0s + u < n2) {
+#pragma unroll
+          for (int k8 = 0; k8 < 4; ++k8)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[u][k8][jj], sw[u][k8][jj], v, 0, 0, 0);
+        }
     }
   }
   // ---- epilogue of the 32-voxel x 32-channel sub-block (same arithmetic as the direct kernel's) ------------
@@ -252,7 +299,7 @@ size_t conv_wino_lds(int bz, int by, int bx) {
 }
 
 bool conv_wino_ok(const ConvArgs &a) {
-  return a.ntaps == 27 && a.td == 3 && a.stride == 1 && !a.par && !a.ups && a.ks <= 1 && a.bs == 1 && !a.s2w &&
+  return a.ntaps == 27 && a.td == 3 && a.stride == 1 && !a.par && !a.ups && a.ks <= 1 && a.bs == 1 && (!a.s2w || (a.s2C0 % 32 == 0 && a.s2C1 % 32 == 0)) &&
          a.C0 % 16 == 0 && a.C1 % 16 == 0 && conv_wino_tile_ok(a.bz, a.by, a.bx) && a.Zo % a.bz == 0 && a.Yo % a.by == 0 &&
          a.Xo % a.bx == 0 && a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo;
 }

@@ -704,7 +704,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     if (upload(m, zb, &op.d_zero_bias)) return 1;
   }
   // fuse the 1x1x1 skip conv when this conv runs on the 27-tap register-ring path without K split
-  if (s.skip0 && s.ntaps == 27 && !parity && a.CK == 32 && !op.small_n && !op.wino && s.stride == 1 &&
+  if (s.skip0 && s.ntaps == 27 && !parity && a.CK == 32 && !op.small_n && (!op.wino || op.NB == 1) && s.stride == 1 &&
       s.skip0->C % 32 == 0 && (!s.skip1 || s.skip1->C % 32 == 0) && !getenv("CM_NO_FUSE_SKIP")) {
     const Param &w2 = P(m, s.skip_w);
     const Param &b2 = P(m, s.skip_b);
@@ -1016,7 +1016,7 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   }
   if (ca.resid) ca.resid += (size_t)b0 * Vo * ca.res_cs;
   if (op.d_s2w && !m->train_fwd) {
-    if (32 * op.MB > cm::conv_halo_voxels(ca)) return fail("fused skip conv: tile rows exceed the staged box");
+    if (!op.wino && 32 * op.MB > cm::conv_halo_voxels(ca)) return fail("fused skip conv: tile rows exceed the staged box");
     ca.s2w = op.d_s2w;
     ca.s2src0 = op.skip0->d + (size_t)b0 * Vo * op.skip0->C; ca.s2C0 = op.skip0->C;
     ca.s2src1 = op.skip1 ? op.skip1->d + (size_t)b0 * Vo * op.skip1->C : nullptr; ca.s2C1 = op.skip1 ? op.skip1->C : 0;
