@@ -9,7 +9,7 @@
 // matrix instructions for the same fp32 result up to rounding (measured error vs the reference: see the
 // parity tests; the transforms only add / subtract and scale weights by 1/2, 1/4).
 //
-// One 256-thread workgroup = one sample's BZ x BY x BX output box (BZ * (BY/2) * (BX/2) = 32 patch rows):
+// One 256-thread workgroup = one sample's BZ x BY x BX output box (BZ * (BY/2) * (BX/2) <= 32 patch rows):
 //   * per 16-channel chunk every thread item (input plane zi, patch, channel quad) loads its 4x4 input
 //     patch straight from global memory (GroupNorm affine + SiLU + Dropout3d multiplier applied on the fly,
 //     zero padding as a mask), applies B^T d B in registers and writes the 16 frequency components to LDS as
@@ -31,10 +31,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-template <int BZ, int BY, int BX, int OCC>
+// Tile = BZ planes x PY x PX patches (2x2 outputs each), ROWS = BZ * PY * PX <= 32 rows of the accumulator block
+// (rows beyond ROWS are padding).  Where the patch grid is not a multiple of PY / PX the LAST tile of a row is
+// shifted back inside the grid; it recomputes a few patches of its neighbour but owns (stores, counts in the
+// statistics) only its own ones -- a.ntx / a.nty tiles of step PX / PY patches.
+template <int BZ, int PY, int PX, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
-  constexpr int PY = BY / 2, PX = BX / 2, NP = PY * PX;
-  static_assert(BZ * NP == 32, "one 32-row accumulator block per frequency component");
+  constexpr int NP = PY * PX, ROWS = BZ * NP;
+  static_assert(ROWS <= 32 && ROWS > 16, "one (partly filled) 32-row accumulator block per frequency component");
   constexpr int HZ = BZ + 2, UR = HZ * NP;      // input planes, rows per component in LDS
   constexpr int CS = 16, S = CS + 4;            // channel chunk, LDS row stride (conflict-free b128 for consecutive rows)
   constexpr int NITEMS = HZ * NP * (CS / 4);    // staging items: (plane, patch, channel quad)
@@ -53,14 +57,18 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
   const int tz = tile % a.ntz;
   const int b0 = tile / a.ntz;
   const int nt = blockIdx.y;
-  const int z0 = tz * BZ, y0 = ty * BY, x0 = tx * BX;
+  // patch origin of the tile (shifted back inside the grid if it would stick out) and the first patch it OWNS
+  const int pyt = a.Yo >> 1, pxt = a.Xo >> 1;
+  const int py0 = min(ty * PY, pyt - PY), px0 = min(tx * PX, pxt - PX);
+  const int z0 = tz * BZ, y0 = 2 * py0, x0 = 2 * px0;
   const int bs = b0 < a.B ? b0 : 0;             // (grid is exact; kept for safety)
 
   if (tid < 128) {
     const int ab = tid >> 5, row = tid & 31;
     const int zr = row / NP, pr = row % NP, py = pr / PX, px = pr % PX;
     const int oz = z0 + zr, oy = y0 + 2 * py + (ab >> 1), ox = x0 + 2 * px + (ab & 1);
-    outoff[tid] = (b0 < a.B && oz < a.Zo && oy < a.Yo && ox < a.Xo) ? ((b0 * a.Zo + oz) * a.Yo + oy) * a.Xo + ox : -1;
+    const bool own = row < ROWS && py0 + py >= ty * PY && px0 + px >= tx * PX;
+    outoff[tid] = (own && b0 < a.B && oz < a.Zo && oy < a.Yo && ox < a.Xo) ? ((b0 * a.Zo + oz) * a.Yo + oy) * a.Xo + ox : -1;
   }
   // ---- this thread's staging item: source voxel offsets of its 4x4 patch, resolved once ---------------
   const bool stager = tid < NITEMS;
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
   for (int x = 0; x < 4; ++x) bq[0][x] = wbase[x * 64];
 
-  const float *arow = U + (size_t)(wave * 4) * UR * S + (size_t)r * S + 4 * hh;   // component xi_y = wave, xi_x = 0, tap 0
+  const float *arow = U + (size_t)(wave * 4) * UR * S + (size_t)min(r, ROWS - 1) * S + 4 * hh;   // component xi_y = wave, xi_x = 0, tap 0
 
   for (int ch = 0; ch < nchunks; ++ch) {
     const float *src;
@@ -286,10 +294,29 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
   }
 }
 
-// tile shapes with BZ * (BY/2) * (BX/2) == 32
+// instantiated tiles (bz planes, by / 2 x bx / 2 patches): full resolution 8 x 2 x 2 (32 rows), half resolution of the
+// ATC / 2x grids 2 x 3 x 5 (30 rows), half resolution of the CR-120 grid 2 x 7 x 2 (28 rows)
+#define CM_WINO_TILES(X) X(8, 2, 2) X(2, 3, 5) X(2, 7, 2)
+
 bool conv_wino_tile_ok(int bz, int by, int bx) {
-  return (bz == 8 && by == 4 && bx == 4) || (bz == 4 && by == 4 && bx == 8) || (bz == 4 && by == 8 && bx == 4) ||
-         (bz == 2 && by == 8 && bx == 8);
+#define X(z, py, px) if (bz == z && by == 2 * py && bx == 2 * px) return true;
+  CM_WINO_TILES(X)
+#undef X
+  return false;
+}
+
+bool conv_wino_pick(int Zo, int Yo, int Xo, int *bz, int *by, int *bx) {
+  if (Yo % 2 || Xo % 2) return false;
+  double best = 0;
+#define X(z, py, px)                                                                                          \
+  if (Zo % z == 0 && 2 * py <= Yo && 2 * px <= Xo) {                                                          \
+    const int ny = (Yo / 2 + py - 1) / py, nx = (Xo / 2 + px - 1) / px;                                       \
+    const double eff = (double)(Yo / 2) * (Xo / 2) / ((double)ny * py * nx * px) * (z * py * px) / 32.0;      \
+    if (eff > best) { best = eff; *bz = z; *by = 2 * py; *bx = 2 * px; }                                      \
+  }
+  CM_WINO_TILES(X)
+#undef X
+  return best >= 0.6;
 }
 
 size_t conv_wino_lds(int bz, int by, int bx) {
@@ -300,8 +327,9 @@ size_t conv_wino_lds(int bz, int by, int bx) {
 
 bool conv_wino_ok(const ConvArgs &a) {
   return a.ntaps == 27 && a.td == 3 && a.stride == 1 && !a.par && !a.ups && a.ks <= 1 && a.bs == 1 && (!a.s2w || (a.s2C0 % 32 == 0 && a.s2C1 % 32 == 0)) &&
-         a.C0 % 16 == 0 && a.C1 % 16 == 0 && conv_wino_tile_ok(a.bz, a.by, a.bx) && a.Zo % a.bz == 0 && a.Yo % a.by == 0 &&
-         a.Xo % a.bx == 0 && a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo;
+         a.C0 % 16 == 0 && a.C1 % 16 == 0 && conv_wino_tile_ok(a.bz, a.by, a.bx) && a.Zo % a.bz == 0 && a.Yo % 2 == 0 && a.Xo % 2 == 0 &&
+         a.by <= a.Yo && a.bx <= a.Xo && a.nty == (a.Yo + a.by - 1) / a.by && a.ntx == (a.Xo + a.bx - 1) / a.bx && a.ntz == a.Zo / a.bz &&
+         a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo && conv_wino_lds(a.bz, a.by, a.bx) <= 80 * 1024;
 }
 
 hipError_t launch_conv_wino(const ConvArgs &a_in, hipStream_t st) {
@@ -310,13 +338,22 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, hipStream_t st) {
   if (!conv_wino_ok(a)) return hipErrorInvalidValue;
   const dim3 grid((unsigned)(a.B * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + 31) / 32));
   const size_t lds = conv_wino_lds(a.bz, a.by, a.bx);
-#define CM_WINO(z, y, x)                                                                            \
-  if (a.bz == z && a.by == y && a.bx == x) {                                                        \
-    hipLaunchKernelGGL((conv_wino_kernel<z, y, x, 2>), grid, dim3(256), lds, st, a);                \
+#define X(z, py, px)                                                                                \
+  if (a.bz == z && a.by == 2 * py && a.bx == 2 * px) {                                              \
+    static bool attr_set[64] = {false};                                                             \
+    int dev = 0;                                                                                    \
+    (void)hipGetDevice(&dev);                                                                       \
+    if (!attr_set[dev & 63]) {                                                                      \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<z, py, px, 2>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+      if (e != hipSuccess) return e;                                                                \
+      attr_set[dev & 63] = true;                                                                    \
+    }                                                                                               \
+    hipLaunchKernelGGL((conv_wino_kernel<z, py, px, 2>), grid, dim3(256), lds, st, a);              \
     return hipGetLastError();                                                                       \
   }
-  CM_WINO(8, 4, 4) CM_WINO(4, 4, 8) CM_WINO(4, 8, 4) CM_WINO(2, 8, 8)
-#undef CM_WINO
+  CM_WINO_TILES(X)
+#undef X
   return hipErrorInvalidValue;
 }
 

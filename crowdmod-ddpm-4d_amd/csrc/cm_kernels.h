@@ -94,12 +94,15 @@ size_t conv_first_lds(const ConvArgs &a, int cin);
 hipError_t launch_conv_first(const ConvArgs &a, int cin, const float *wpk, hipStream_t st);
 
 // Winograd F(2x2, 3x3) over (Y, X), direct over Z (cm_conv_wino.hip): stride-1 3x3x3 convs whose output box
-// tiles as bz x by x bx with bz * (by/2) * (bx/2) == 32.  a.wfrag: [Co/32][Ci/16][4 = xi_y][24 = (dz*2 + k8)*4 + xi_x]
+// tiles as bz x by x bx with 16 < bz * (by/2) * (bx/2) <= 32 (cm_conv_wino.hip lists the instantiated shapes; a last
+// tile that would stick out is shifted back and owns only its own patches).  a.wfrag: [Co/32][Ci/16][4 = xi_y][24 = (dz*2 + k8)*4 + xi_x]
 // [64 lanes][4] transformed weights; statistics slots per tile: 4 (the (a, b) sub-blocks).
 bool conv_wino_tile_ok(int bz, int by, int bx);
 bool conv_wino_ok(const ConvArgs &a);
 size_t conv_wino_lds(int bz, int by, int bx);
 hipError_t launch_conv_wino(const ConvArgs &a, hipStream_t st);
+// tile (bz, by, bx) the Winograd kernel would use for an output grid, or false if none of its shapes fits
+bool conv_wino_pick(int Zo, int Yo, int Xo, int *bz, int *by, int *bx);
 
 // ---- small kernels --------------------------------------------------------
 // Per-(sample, slice, channel) mean and M2 of a channels-last tensor.

@@ -595,6 +595,13 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   if (!a.CK) return fail("conv %s: channel counts %d/%d not multiples of 8", s.wname.c_str(), a.C0, a.C1);
   a.nch0 = a.C0 / a.CK; a.nch1 = a.C1 / a.CK;
   op.NB = s.Co > 32 ? 2 : 1;
+  // full- and half-resolution stride-1 3x3x3 layers: Winograd F(2x2,3x3) over (Y, X) -- 2.25x fewer matrix
+  // instructions (cm_conv_wino.hip); its workgroups own one 32-channel output tile each
+  {
+    int wz = 0, wy = 0, wx = 0;
+    op.wino = s.ntaps == 27 && s.stride == 1 && !s.ups && a.C0 % 16 == 0 && a.C1 % 16 == 0 && s.Co % 32 == 0 && s.Co == s.out->C &&
+              s.ci_valid < 0 && s.out->V() > 64 && cm::conv_wino_pick(s.out->Z, s.out->Y, s.out->X, &wz, &wy, &wx) && !getenv("CM_NO_WINO");
+  }
   // tiny-spatial layers are overhead-bound, not throughput-bound: fewer, fatter workgroups
   // (all 128 output channels per workgroup, K split over workgroups) amortise the per-workgroup
   // fixed costs over 4x the matrix work
@@ -602,7 +609,8 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   // measured no better than two NB = 2 workgroups: opt-in only)
   if (s.ntaps == 27 && s.out->V() <= 64 && s.Co % 128 == 0 && getenv("CM_FAT_TILES")) op.NB = 4;
   if (s.ntaps == 27 && s.out->V() <= 64 && getenv("CM_QR_NB")) op.NB = atoi(getenv("CM_QR_NB"));
-  if (s.ntaps == 27 && s.out->V() > 64) {
+  if (op.wino) op.NB = 1;
+  if (s.ntaps == 27 && s.out->V() > 64 && !op.wino) {
     if (const TunedTile *t = find_tuned(a, 0)) op.NB = t->NB;
     // tuner policies (tools/tune_tiles.py): N blocking of the 64- / 128-channel 3x3x3 layers
     if (s.Co == 64 && getenv("CM_NB64")) op.NB = atoi(getenv("CM_NB64"));
@@ -643,18 +651,10 @@ int add_conv(cm_model *m, const ConvSpec &s) {
           }
     if (upload(m, ws, &op.d_wsmall)) return 1;
   }
-  // full-resolution stride-1 3x3x3 layers: Winograd F(2x2,3x3) over (Y, X) -- 2.25x fewer matrix instructions
-  {
-    static const int wz[4][3] = {{8, 4, 4}, {4, 4, 8}, {4, 8, 4}, {2, 8, 8}};
-    bool tiles = false;
-    for (auto &t : wz) tiles = tiles || (s.out->Z % t[0] == 0 && s.out->Y % t[1] == 0 && s.out->X % t[2] == 0);
-    if (s.ntaps == 27 && s.stride == 1 && !s.ups && a.C0 % 16 == 0 && a.C1 % 16 == 0 && s.Co % 32 == 0 && s.Co == s.out->C &&
-        Ci_ref == Ci_pad && tiles && s.out->V() > 64 && !getenv("CM_NO_WINO")) {
-      op.wino = true;
-      std::vector<float> ww;
-      pack_wino(&wi, nullptr, s.Co, Ci_ref, Ci_pad, &ww, nullptr, nullptr);
-      if (upload(m, ww, &op.d_wwino)) return 1;
-    }
+  if (op.wino) {
+    std::vector<float> ww;
+    pack_wino(&wi, nullptr, s.Co, Ci_ref, Ci_pad, &ww, nullptr, nullptr);
+    if (upload(m, ww, &op.d_wwino)) return 1;
   }
   // the UNet's first conv (C <= 8 data channels -> base): dedicated kernel, whole weight set in registers
   if (s.s0 == m->x8_act && s.ntaps == 27 && s.stride == 1 && !s.ups && !s.gn && !s.temb && !s.resid && !s.s1 &&
@@ -966,12 +966,10 @@ int build_time_table(cm_model *m) {
 int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   if (op.skip_if_fused && !m->train_fwd) return 0;  // absorbed by the block's conv_2 (inference plan)
   if (op.tuned_B < 0 && op.wino) {
-    static const int wz[4][3] = {{8, 4, 4}, {4, 4, 8}, {4, 8, 4}, {2, 8, 8}};
     cm::ConvArgs &a = op.ca;
     a.bs = 1;
-    for (auto &t : wz)
-      if (a.Zo % t[0] == 0 && a.Yo % t[1] == 0 && a.Xo % t[2] == 0) { a.bz = t[0]; a.by = t[1]; a.bx = t[2]; break; }
-    a.ntz = a.Zo / a.bz; a.nty = a.Yo / a.by; a.ntx = a.Xo / a.bx;
+    if (!cm::conv_wino_pick(a.Zo, a.Yo, a.Xo, &a.bz, &a.by, &a.bx)) return fail("no Winograd tile for %s", op.label.c_str());
+    a.ntz = a.Zo / a.bz; a.nty = (a.Yo + a.by - 1) / a.by; a.ntx = (a.Xo + a.bx - 1) / a.bx;
     op.MB = 4;                       // statistics slots per tile: the four (a, b) output sub-blocks
     op.tuned_B = B;
     if (!cm::conv_wino_ok(a)) return fail("Winograd tile does not fit %s", op.label.c_str());
