@@ -337,6 +337,59 @@ class DDPM_model:
         self.denoiser.load_state_dict(checkpoint.load_model_state(model_fullname))
         return self
 
+    def generate_metrics(self, batched_test_data, chunkRepdPastSeq, metric, batches_to_use, samples_per_batch,
+                         model_fullname=None, output_dir=None, *, rng: Optional[np.random.Generator] = None, eps=None):
+        """ddpm.py:336-392: per test batch draw `samples_per_batch / chunkRepdPastSeq` past windows, repeat each
+        `chunkRepdPastSeq` times (torch.repeat_interleave), sample all `samples_per_batch` chains (NSAMPLES = 1280 =
+        64 pasts x 20 repeats in config/ATC.yml) in ONE device loop, and hand predictions / ground truth to the
+        MetricsGenerator -- whose per-frame reductions run on the device as well (cm_frame_metrics), so neither the
+        1280 samples' Python double loop nor a `.cpu()` round trip per sample remains.  Returns the MetricsGenerator;
+        with `output_dir` its tables are written there as CSV + metrics_files.json (utils/metrics/metricsGenerator.py:
+        342-358).  metric: PSNR | MASK_PSNR | RE_DENSITY | TV | ALL (SSIM, motion-feature and energy metrics are CPU
+        library code on the reference side and out of scope here)."""
+        import logging
+        from .metrics import MetricsGenerator, compute_metrics
+        r = self.res
+        if model_fullname is not None:
+            self.load_checkpoint(model_fullname)
+        sampler = DDPM(timesteps=r.timesteps, scale=r.scale, device=self.device)
+        rng = rng or np.random.default_rng(42)
+        samples_per_batch, chunk = int(samples_per_batch), int(chunkRepdPastSeq)
+        preds, gts, count = [], [], 0
+        for past_test, future_test in batched_test_data:
+            past_test = np.asarray(past_test, dtype=np.float32)
+            future_test = np.asarray(future_test, dtype=np.float32)
+            n = past_test.shape[0]
+            idx = rng.permutation(n) if n < samples_per_batch else rng.permutation(n)[:samples_per_batch]
+            idx = np.repeat(idx, chunk)[:samples_per_batch]            # repeat_interleave, then the first samples_per_batch
+            pasts, futures = past_test[idx], future_test[idx]
+            nb = len(idx)
+            self.denoiser.max_batch = max(self.denoiser.max_batch, nb)
+            logging.info("Computing sampling on batch %d: %d chains (%d pasts x %d repeats)", count + 1, nb, -(-nb // chunk), chunk)
+            if r.sampler == "DDPM":
+                x, _ = self._generate_ddpm(pasts, sampler, nb)
+                logging.info("L1 norm %.2f using %s guidance", float(np.mean(np.abs(x[:, 0]))), r.guidance)
+            elif r.sampler == "DDIM":
+                x, _ = self._generate_ddim(pasts, np.arange(0, r.timesteps - 1, r.ddim_divider), sampler, nb)
+            else:
+                raise ValueError(f"{r.sampler} sampler not supported")
+            preds.append(x)
+            gts.append(futures)
+            count += 1
+            if count == int(batches_to_use):
+                break
+        if not preds:
+            raise ValueError("empty test data")
+        mg = MetricsGenerator(np.concatenate(preds), np.concatenate(gts), self.mprops_count, device=self.device)
+        if eps is None:
+            mp = self.cfg.get("MACROPROPS", {}) if hasattr(self.cfg, "get") else {}
+            eps = float(mp.get("EPS", 1e-6)) if hasattr(mp, "get") else 1e-6
+        compute_metrics(mg, metric, chunk, eps)
+        if output_dir:
+            title = f"{r.batch_size * chunk * count} samples in total (BS:{r.batch_size}, Rep:{chunk}, TB:{count})-({self.arch})"
+            mg.save_data_metrics(output_dir, title, samples_per_batch)
+        return mg
+
     def sampling(self, batched_test_data, plotType=None, model_fullname=None, plotMprop=None, plotPast=None,
                  samePastSeq=False, macropropPlotter=None, *, rng: Optional[np.random.Generator] = None):
         """ddpm.py:284-334 without the matplotlib tail: load the checkpoint, take the first

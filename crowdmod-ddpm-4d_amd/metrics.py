@@ -32,6 +32,7 @@ class MetricsGenerator:
         mm = np.empty((N, C_, F, 2), dtype=np.float32)
         native.check(native.lib().cm_frame_metrics(device, dp.ptr, dg.ptr, N, C_, H, W, F, out.ctypes.data, mm.ctypes.data))
         self.N, self.F, self.npix = N, F, H * W
+        self._pred_gt = (pred, gt)
         self._red = out
         m = self.mprops_count
         # _get_mprops_ranges (metricsGenerator.py:44-68): global max - global min of the ground truth per property
@@ -83,3 +84,45 @@ class MetricsGenerator:
         m = self.mprops_count
         d = np.abs(self._red[:, :m, :, 3] - self._red[:, :m, :, 4])              # [N, m, F]
         self.data_dict["TV_OVER_TIME"] = np.transpose(d, (0, 2, 1)).reshape(self.N, self.F * m)
+
+    # metricsGenerator.py:342-358 (CSV tables + an index JSON; the reference's boxplots are matplotlib code, not mirrored)
+    def headers(self):
+        names = ["rho", "vx", "vy", "unc"][: self.mprops_count]
+        per_frame = ",".join(f"{n}_f{f + 1}" for f in range(self.F) for n in names)
+        flat = ",".join(names)
+        frames = ",".join(f"f{f + 1}" for f in range(self.F))
+        return {"PSNR": flat, "MAX_PSNR": flat, "PSNR_OVER_TIME": per_frame, "MAX_PSNR_OVER_TIME": per_frame,
+                "MASK_PSNR": flat, "MAX_MASK_PSNR": flat, "MASK_PSNR_OVER_TIME": per_frame, "MAX_MASK_PSNR_OVER_TIME": per_frame,
+                "RE_DENSITY": frames, "MIN_RE_DENSITY": frames, "TV_OVER_TIME": per_frame}
+
+    def save_data_metrics(self, output_dir, title, samples_per_batch):
+        import json
+        import os
+        os.makedirs(output_dir, exist_ok=True)
+        index = {"title": title}
+        for name, header in self.headers().items():
+            data = self.data_dict.get(name)
+            if data is None:
+                continue
+            fn = os.path.join(output_dir, f"{name}_NS{int(samples_per_batch)}.csv")
+            np.savetxt(fn, np.asarray(data, dtype=np.float64), delimiter=",", header=header, comments="")
+            index[name] = fn
+        with open(os.path.join(output_dir, "metrics_files.json"), "w") as fo:
+            json.dump(index, fo, indent=2)
+        return index
+
+
+def compute_metrics(mg: MetricsGenerator, metric: str, chunkRepdPastSeq: int, eps: float):
+    """utils/metrics/metricsGenerator.py:379-395 for the metrics this path implements."""
+    known = ("PSNR", "MASK_PSNR", "RE_DENSITY", "TV", "ALL")
+    if metric not in known:
+        raise ValueError(f"metric {metric!r}: this path computes {known}; SSIM / MF_* / ENERGY are CPU-library metrics of the reference")
+    if metric in ("PSNR", "ALL"):
+        mg.compute_psnr_metric(chunkRepdPastSeq, eps)
+    if metric in ("MASK_PSNR", "ALL"):
+        mg.compute_psnr_metric(chunkRepdPastSeq, eps, masked_flag=True)
+    if metric in ("RE_DENSITY", "ALL"):
+        mg.compute_re_density_metric(chunkRepdPastSeq, eps)
+    if metric in ("TV", "ALL"):
+        mg.compute_tv_metric()
+    return mg

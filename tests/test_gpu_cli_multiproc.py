@@ -1,0 +1,172 @@
+"""GPU tests of the drivers around the hot path: the generate_metrics CLI (64 pasts x N repeats through one
+device loop + device-side reductions), and the multi-process paths on ONE GPU (gloo): two fresh processes each
+run DDPM_model._generate_ddpm on their batch shard and the gathered result must equal the single-process run bit
+for bit; two data-parallel training replicas must stay identical.  Children are spawned before the parent
+touches the GPU and are never re-exec'ed.
+Reference lines: generate_metrics.py:53-79, models/diffusion/ddpm.py:336-392,206-236,156-202."""
+import json
+import multiprocessing as mp
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import FULL_GRIDS, SEED_W, full_cfg, narrow_cfg
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_generate_metrics_cli_runs_one_device_loop_per_batch(tmp_path, monkeypatch):
+    """generate_metrics.py --chunk-repd-past-seq 4: BATCH_SIZE * 4 = 256 chains per test batch (64 pasts x 4 repeats,
+    repeat_interleave order), 3 diffusion steps, all metrics; tables checked against the CPU oracle of the same
+    reductions on the returned predictions."""
+    sys.path.insert(0, ROOT)
+    import yaml
+    import generate_metrics as gm
+    from oracle import metrics_numpy as om
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ATC.yml")))
+    cfg["DATA_FS"]["OUTPUT_DIR"] = str(tmp_path / "out")
+    cfg["DATA_FS"]["SAVE_DIR"] = str(tmp_path / "ckpt") + "/"
+    yml = tmp_path / "atc.yml"
+    yml.write_text(yaml.safe_dump(cfg))
+    mg = gm.main(["--config-yml-file", str(yml), "--chunk-repd-past-seq", "4", "--timesteps", "3", "--batches-to-use", "2",
+                  "--metric", "ALL"])
+    N, F, m, chunk = 2 * 256, 3, 3, 4
+    d = mg.data_dict
+    assert d["PSNR"].shape == (N, m) and d["MAX_PSNR"].shape == (N // chunk, m)
+    assert d["PSNR_OVER_TIME"].shape == (N, F * m) and d["MAX_MASK_PSNR_OVER_TIME"].shape == (N // chunk, F * m)
+    assert d["RE_DENSITY"].shape == (N, F) and d["MIN_RE_DENSITY"].shape == (N // chunk, F) and d["TV_OVER_TIME"].shape == (N, F * m)
+    idx = json.load(open(tmp_path / "out" / "metrics" / "metrics_files.json"))
+    assert "512 samples in total (BS:64, Rep:4, TB:2)" in idx["title"]
+    back = np.loadtxt(idx["MAX_PSNR"], delimiter=",", skiprows=1)
+    np.testing.assert_allclose(back, d["MAX_PSNR"], rtol=1e-12)
+    assert open(idx["PSNR_OVER_TIME"]).readline().startswith("rho_f1,vx_f1,vy_f1,rho_f2")
+    # MAX over each chunk of repeats really is the max of that chunk's rows
+    np.testing.assert_array_equal(d["MAX_PSNR"][5], d["PSNR"][20:24].max(axis=0))
+    # the reductions behind the tables vs the CPU oracle on the same (pred, gt)
+    pred, gt = mg._pred_gt
+    # repeats of one past share the ground truth (repeat_interleave), predictions differ (own noise per chain)
+    assert np.array_equal(gt[0], gt[3]) and not np.array_equal(gt[0], gt[4]) and not np.array_equal(pred[0], pred[1])
+    avg, mx, ot, mxt = om.psnr_tables(pred[:32], gt[:32], chunk, 1e-6, False)
+    # ranges are global (all 512 samples): shift the oracle's 32-sample ranges to the generator's
+    shift = 20 * np.log10(np.asarray(mg.ranges) / np.asarray(om.ranges(gt[:32])))
+    np.testing.assert_allclose(d["PSNR"][:32], avg + shift, rtol=2e-6, atol=1e-6)
+    re, mn = om.re_density(pred[:32], gt[:32], chunk, 1e-6)
+    np.testing.assert_allclose(d["RE_DENSITY"][:32], re, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(d["TV_OVER_TIME"][:8], om.tv_over_time(pred[:8], gt[:8]), rtol=0, atol=5e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _sample_worker(rank, world, port, gb, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from crowdmod_ddpm_4d_amd import distributed as cdist, prng, spec
+    from crowdmod_ddpm_4d_amd.config import AttrDict
+    from crowdmod_ddpm_4d_amd.ddpm_model import DDPM_model
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W = FULL_GRIDS["atc"]
+    cfg = AttrDict({
+        "MACROPROPS": {"ROWS": H, "COLS": W}, "DATASET": {"PAST_LEN": 5, "FUTURE_LEN": 3, "BATCH_SIZE": gb},
+        "MODEL": {"NSAMPLES": gb, "NSAMPLES4PLOTS": 2, "DDPM": {
+            "SAMPLER": "DDPM", "TIMESTEPS": 6, "SCALE": 0.5, "SIGMA": 0.001, "DDIM_DIVIDER": 2, "GUIDANCE": "None",
+            "LAMBDA_GUIDANCE": 0.0,
+            "UNET": {"CONDITION": "Past", "NUM_RES_BLOCKS": 1, "BASE_CH": 32, "BASE_CH_MULT": [1, 2, 4],
+                     "APPLY_ATTENTION": [False, False, True, False], "DROPOUT_RATE": 0.1, "TIME_EMB_MULT": 4}}}})
+    model = DDPM_model(cfg, "DDPM-UNet", 3, device=0, seed=123)
+    model.denoiser.load_state_dict(spec.init_params(full_cfg(3), SEED_W))
+    sampler = DDPM(timesteps=6, scale=0.5, device=0)
+    past = prng.normal_per_sample(7, "mp/past", np.arange(gb), 3 * H * W * 5).reshape(gb, 3, H, W, 5)
+
+    def generate(p, n, base):
+        model._sample_calls = 0
+        return model._generate_ddpm(p, sampler, n, sample_id_base=base)[0]
+
+    full = cdist.sample_sharded(generate, past, gb, rank, world)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), full)
+    if rank == 0 and world > 1:          # the unsharded run on the same device, same seeds
+        np.save(os.path.join(out_dir, "single.npy"), generate(past, gb, 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gb", [8, 7])
+def test_two_processes_sharded_ddpm_sampling_equals_single_process(tmp_path, gb):
+    """contiguous batch blocks per rank, noise addressed by the GLOBAL sample index, one gather at the
+    end -- the gathered x_0 equals the single-process run bit for bit (even and uneven shards)."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    ps = [ctx.Process(target=_sample_worker, args=(r, 2, port, gb, str(tmp_path))) for r in range(2)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    single = np.load(tmp_path / "single.npy")
+    assert np.isfinite(single).all() and single.shape == (gb, 3) + FULL_GRIDS["atc"] + (3,)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"r{r}.npy"), single), r
+
+
+def _train_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from crowdmod_ddpm_4d_amd import distributed as cdist, prng, spec
+    from crowdmod_ddpm_4d_amd.config import AttrDict
+    from crowdmod_ddpm_4d_amd.ddpm_model import DDPM_model
+    import torch.distributed as dist
+    cdist.init_process_group("gloo")
+    B, C_, H, W, P, F = 4, 3, 4, 8, 5, 3
+    cfg = AttrDict({
+        "MACROPROPS": {"ROWS": H, "COLS": W},
+        "DATASET": {"NAME": "synthetic", "PAST_LEN": P, "FUTURE_LEN": F, "BATCH_SIZE": B},
+        "DATA_FS": {"SAVE_DIR": out_dir + "/"},
+        "MODEL": {"NAME": "{}_SYN_TE{}_PL{}_FL{}_CE{}_{}.pth", "DDPM": {"TIMESTEPS": 1000, "SCALE": 0.5, "CHECKPOINTS_TO_KEEP": 0, "UNET": {
+            "CONDITION": "Past", "NUM_RES_BLOCKS": 1, "BASE_CH": 8, "BASE_CH_MULT": [1, 2, 4],
+            "APPLY_ATTENTION": [False, False, True, False], "DROPOUT_RATE": 0.1, "TIME_EMB_MULT": 4,
+            "TRAIN": {"EPOCHS": 3, "SOLVER": {"LR": 2e-3, "BETAS": [0.5, 0.999], "WEIGHT_DECAY": 0.003,
+                      "SCHEDULER": {"FACTOR": 0.5, "PATIENCE": 10, "MIN_LR": 1e-6}}}}}}})
+    model = DDPM_model(cfg, "DDPM-UNet", C_, device=0)
+    model.denoiser.load_state_dict(spec.init_params(narrow_cfg(C_), SEED_W))
+    model.set_data_parallel(rank, world)
+    n = 4 * B
+    past = prng.normal(3, "dp/past", n * C_ * H * W * P).reshape(n, C_, H, W, P)
+    fut = prng.normal(3, "dp/fut", n * C_ * H * W * F).reshape(n, C_, H, W, F)
+    loader = [(past[i:i + B], fut[i:i + B]) for i in range(rank * B, n, world * B)]   # every world-th batch
+    hist = model.train(loader, grad_sync=cdist.GradAverager(), loss_sync=cdist.mean_over_ranks, save=False)
+    sd = model.denoiser.state_dict()
+    np.savez(os.path.join(out_dir, f"dp{rank}.npz"), hist=np.asarray(hist), lr=model._lr,
+             w=sd["decoder_blocks.7.conv_2.weight"], b=sd["final.2.bias"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_data_parallel_replicas_stay_identical(tmp_path):
+    """Plain data parallelism (SURVEY 8e "next"): gradients averaged every step (gloo here, RCCL on the node), epoch loss
+    averaged for the scheduler -- both replicas must end with identical weights, loss history and learning rate,
+    and must have trained (different data / noise per rank, same update)."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    ps = [ctx.Process(target=_train_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    a, b = np.load(tmp_path / "dp0.npz"), np.load(tmp_path / "dp1.npz")
+    assert np.array_equal(a["hist"], b["hist"]) and float(a["lr"]) == float(b["lr"]) and len(a["hist"]) == 3
+    assert np.array_equal(a["w"], b["w"]) and np.array_equal(a["b"], b["b"])
+    assert np.isfinite(a["hist"]).all() and a["hist"][-1] < a["hist"][0]
