@@ -1,28 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark: denoise-steps/sec of the DDPM-UNet reverse loop.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (BASELINE configs[1], the headline)
+    python bench.py --mode train                              (configs[2]: training step, B = 128, own JSON line)
+    python bench.py --dtype f16 --grid 24x72 --batch 32       (configs[4]: doubled grid, f16 matrix cores, own line)
 
-Workload (BASELINE.json configs[1]): config/ATC.yml sampling, batch 64 per GPU,
-T = 1000 schedule, tensors [B,4,12,36,(5 past + 3 future)] -- synthetic inputs,
-random-init weights (torch-default init ranges from the repo PRNG).  A "step" is
-one pass of the hot path over the batch: 1 UNet forward + 1 sampler update
-(/root/reference/models/diffusion/ddpm.py:214-221).  K steps are the first K
-visited timesteps of the 1000-step loop, run on the device behind ONE C-ABI call.
+Workload of the default run (BASELINE.json configs[1]): config/ATC.yml sampling, batch 64 per GPU, T = 1000
+schedule, tensors [B,4,12,36,(5 past + 3 future)] -- synthetic inputs, random-init weights (torch-default init
+ranges from the repo PRNG).  A "step" is one pass of the hot path over the batch: 1 UNet forward + 1 sampler
+update (/root/reference/models/diffusion/ddpm.py:214-221).  The K timed steps are the first K visited timesteps
+of the 1000-step loop, run on the device behind ONE C-ABI call; the K-step region (barrier + device sync on both
+sides, max over ranks) is repeated `--repeats` times and the MEDIAN is reported.
 
-N > 1: launched by torch.distributed.run, one rank per GPU; the batch of
-independent chains is sharded (64 per GPU, weak scaling), the only collective is
-one RCCL all_gather of x at the end of the region.
+N > 1: launched by torch.distributed.run, one rank per GPU; the batch of independent chains is sharded with
+crowdmod-ddpm-4d_amd/distributed.py (64 chains per GPU, weak scaling); the only collective is the gather of x_0
+at the end of every timed region (RCCL over xGMI).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the 3x3x3 MFMA
-conv, timed with HIP events on its launch stream) and, at N=1, `cpu_baseline`
-(this repo's torch-functional CPU restatement of the reference path, i.e. the
-same ATen CPU kernels the reference dispatches to, on the host cores).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel class = the 3x3x3 conv launches, timed with HIP
+events on their launch stream; algorithmic AND executed-FLOP fractions of the fp32 MFMA peak) and, at N = 1,
+`cpu_baseline` (this repo's torch-functional CPU restatement of the reference path -- the same ATen CPU kernels the
+reference dispatches to -- on the host cores, thread count chosen by a short sweep).
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -33,28 +36,41 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 (= fp32 vector peak)
+F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide: dense f16/bf16 MFMA peak (the headline figures with sparsity are 2x)
 
 
-def load_cfg(channels: int):
+def load_cfg():
     from crowdmod_ddpm_4d_amd import config as cfgmod
     cfg = cfgmod.getYamlConfig(os.path.join(ROOT, "config", "ATC.yml"))
     return cfg, cfgmod.resolve(cfg, "DDPM-UNet")
 
 
+def csrc_sha16():
+    """Fingerprint of the kernel sources: a PMC measurement is only quoted for the build it was taken on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "crowdmod-ddpm-4d_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".cpp", ".inc", ".h")) and "selftest" not in fn:
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def hbm_traffic():
-    """HBM bytes per launch of the dominant kernel class, from the rocprofv3 PMC passes of
-    tools/profile_round.sh (FETCH_SIZE x2-corrected + WRITE_SIZE; see profiles/hbm_traffic.json).
-    bench.py cannot collect PMC counters on itself, so the committed measurement is quoted."""
+    """HBM bytes per launch of the dominant kernel class from the rocprofv3 PMC passes of tools/profile_round.sh
+    (FETCH_SIZE x2-corrected + WRITE_SIZE, separate passes; profiles/hbm_traffic.json).  bench.py cannot collect
+    PMC counters on itself; the committed measurement is quoted only if it was taken on THIS build of the kernels."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as fo:
-        return json.load(fo).get("hbm_bytes_per_launch")
+        j = json.load(fo)
+    return j.get("hbm_bytes_per_launch") if j.get("csrc_sha16") == csrc_sha16() else None
 
 
 def cpu_baseline(res, channels: int, batch: int, budget_s: float):
-    """Time the CPU port (oracle/unet_torch.py) on a bounded sample of the same workload."""
+    """Time the CPU port (oracle/unet_torch.py) on a bounded sample of the same workload; the thread count is
+    chosen by a one-step probe per candidate (more threads than physical cores was slower on the round-1 box)."""
     import torch
     from crowdmod_ddpm_4d_amd import prng, spec
     from oracle import unet_torch as ot
@@ -69,7 +85,17 @@ def cpu_baseline(res, channels: int, batch: int, budget_s: float):
     x = torch.from_numpy(prng.normal(7, "bench/xT", int(np.prod(shape_f))).reshape(shape_f))
     z = torch.from_numpy(prng.normal(7, "bench/z", int(np.prod(shape_f))).reshape(shape_f))
     T = res.timesteps
-    ot.generate_ddpm(P, plan, sched, past, x, lambda t: z, T, t_list=[T - 1])  # warm-up step
+    ncpu = os.cpu_count() or 1
+    cands = sorted({c for c in (8, 16, 32, 64, 96, 128, ncpu // 2, ncpu) if 1 <= c <= ncpu})
+    ot.generate_ddpm(P, plan, sched, past, x, lambda t: z, T, t_list=[T - 1])  # warm-up step (allocator, oneDNN primitives)
+    probe = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        t0 = time.perf_counter()
+        ot.generate_ddpm(P, plan, sched, past, x, lambda t: z, T, t_list=[T - 1])
+        probe[c] = time.perf_counter() - t0
+    best = min(probe, key=probe.get)
+    torch.set_num_threads(best)
     n, t0 = 0, time.perf_counter()
     while True:
         x = ot.generate_ddpm(P, plan, sched, past, x, lambda t: z, T, t_list=[T - 2 - n])
@@ -77,21 +103,80 @@ def cpu_baseline(res, channels: int, batch: int, budget_s: float):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 50:
             break
-    return {"value": n / el, "unit": "denoise-steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"{n} steps of the B={batch} ATC loop after 1 warm-up step (torch {torch.__version__} CPU, "
-                      f"oracle/unet_torch.py)"}
+    return {"value": n / el, "unit": "denoise-steps/s", "cores": int(best), "kind": "port",
+            "sample": f"{n} steps of the B={batch} ATC loop after a warm-up step (torch {torch.__version__} CPU, "
+                      f"oracle/unet_torch.py); threads swept over {cands}: "
+                      + ", ".join(f"{c}: {1.0 / probe[c]:.2f}/s" for c in cands) + f"; host has {ncpu} logical CPUs"}
+
+
+def run_train(a):
+    """BASELINE configs[2]: config/ATC.yml training step (q-sample + UNet fwd with Dropout3d + MSE + bwd + Adam),
+    batch 128, one MI355X, fp32, inputs resident in HBM; one native call per step."""
+    from crowdmod_ddpm_4d_amd import native, prng, spec
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    from crowdmod_ddpm_4d_amd.unet import UNet
+    _, res = load_cfg()
+    B, Cc = a.batch or 128, 3
+    H, W, P, F = res.rows, res.cols, res.past_len, res.future_len
+    net = UNet(input_channels=Cc, output_channels=Cc, num_res_blocks=res.num_res_blocks, base_channels=res.base_ch,
+               base_channels_multiples=res.base_ch_mult, apply_attention=res.apply_attention, dropout_rate=res.dropout_rate,
+               time_multiple=res.time_emb_mult, condition="Past", max_batch=B)
+    net.load_state_dict(spec.init_params(net.cfg, 42))
+    net.ensure(H, W, P, F, B)
+    net.train_init(lr=5e-5, betas=(0.5, 0.999), weight_decay=0.003)
+    sched = DDPM(timesteps=res.timesteps, scale=res.scale)
+    fut = prng.normal(7, "bt/fut", B * Cc * H * W * F).reshape(B, Cc, H, W, F)
+    past = prng.normal(7, "bt/past", B * Cc * H * W * P).reshape(B, Cc, H, W, P)
+    eps = prng.normal(7, "bt/eps", fut.size).reshape(fut.shape)
+    t = (np.arange(B, dtype=np.int64) * 7919) % res.timesteps
+    dfut, dpast, deps, dt = (native.DeviceBuffer.from_array(x) for x in (fut, past, eps, t))
+    losses = []
+    for _ in range(max(1, a.warmup)):
+        losses.append(net.train_step(sched._handle, dfut, dpast, dt, deps, seed=1, apply_update=True))
+    steps = a.steps if a.steps is not None else 10
+    times = []
+    for _ in range(a.repeats):
+        native.check(native.lib().cm_device_synchronize(0))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            losses.append(net.train_step(sched._handle, dfut, dpast, dt, deps, seed=1, apply_update=True))
+        native.check(native.lib().cm_device_synchronize(0))
+        times.append((time.perf_counter() - t0) / steps)
+    dt_s = float(np.median(times))
+    fwd_flops, fwd_bytes = net.cost(B)
+    ach = 3 * fwd_flops / dt_s / 1e12
+    print(json.dumps({
+        "metric": "train-steps/sec (q-sample + UNet fwd + MSE + bwd + Adam) at ATC [B,3,T,H,W]", "value": 1.0 / dt_s,
+        "unit": "train-steps/s (each over a batch of %d windows)" % B, "n_gpus": 1, "steps": steps, "warmup": a.warmup,
+        "ms_per_step": dt_s * 1e3, "repeat_ms_per_step": [x * 1e3 for x in times], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "samples_per_s": B / dt_s,
+        "config": {"workload": "config/ATC.yml training step (BASELINE configs[2]), batch %d, fp32 (the reference trains under "
+                               "fp16 autocast: this is the wider type)" % B, "channels": Cc, "grid": [H, W]},
+        "roofline": {"kernel": "whole training step (forward + data-gradient + weight-gradient convolutions on v_mfma_f32_32x32x2_f32)",
+                     "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "algorithmic_gflop_per_step": 3 * fwd_flops / 1e9,
+                     "note": "algorithmic FLOPs = 3 x forward (SURVEY 8d estimate: forward + dgrad + wgrad)"},
+        "loss_first": losses[0], "loss_last": losses[-1]}))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="chains per GPU")
+    ap.add_argument("--repeats", type=int, default=5, help="timed K-step regions; the median is reported")
+    ap.add_argument("--batch", type=int, default=None, help="chains per GPU (default 64; 128 windows in --mode train)")
     ap.add_argument("--channels", type=int, default=4)
+    ap.add_argument("--mode", choices=("sample", "train"), default="sample")
+    ap.add_argument("--dtype", choices=("f32", "f16"), default="f32", help="matrix-core operand type of the 3x3x3 convs")
+    ap.add_argument("--grid", type=str, default=None, help="HxW instead of config/ATC.yml's 12x36 (e.g. 24x72, 28x24)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     a = ap.parse_args()
+    if a.mode == "train":
+        return run_train(a)
+    steps = a.steps if a.steps is not None else 50
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -102,7 +187,7 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus={a.gpus}")
 
     import torch
-    from crowdmod_ddpm_4d_amd import native, prng
+    from crowdmod_ddpm_4d_amd import distributed as cdist, native, prng
     from crowdmod_ddpm_4d_amd.ddpm_model import DDPM_model
     from crowdmod_ddpm_4d_amd.diffusion import DDPM
 
@@ -122,19 +207,27 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    cfg, res = load_cfg(a.channels)
-    Cn, B = a.channels, a.batch
+    cfg, res = load_cfg()
+    if a.grid:
+        H, W = (int(v) for v in a.grid.lower().split("x"))
+        cfg.MACROPROPS.ROWS, cfg.MACROPROPS.COLS = H, W
+        from crowdmod_ddpm_4d_amd import config as cfgmod
+        res = cfgmod.resolve(cfg, "DDPM-UNet")
+    Cn, B = a.channels, (a.batch or 64)
     model = DDPM_model(cfg, "DDPM-UNet", Cn, device=local_rank, seed=42)
     model.denoiser.max_batch = B
+    if a.dtype != "f32":
+        model.denoiser.set_precision(a.dtype)
     sampler = DDPM(timesteps=res.timesteps, scale=res.scale, device=local_rank)
     dev = torch.device("cuda", local_rank)
-    gid0 = rank * B  # global index of this shard's first chain
-    shape_p = (B, Cn, res.rows, res.cols, res.past_len)
+    gb = world * B                                    # weak scaling: B chains per GPU
+    lo, hi = cdist.shard_range(gb, rank, world)       # this rank's contiguous block of the global batch
+    shape_p = (hi - lo, Cn, res.rows, res.cols, res.past_len)
     per_p = int(np.prod(shape_p[1:]))
-    past = torch.from_numpy(prng.normal_per_sample(7, "bench/past", np.arange(gid0, gid0 + B), per_p).reshape(shape_p)).to(dev)
+    past = torch.from_numpy(prng.normal_per_sample(7, "bench/past", np.arange(lo, hi), per_p).reshape(shape_p)).to(dev)
 
     def run(nsteps):
-        x, _ = model._generate_ddpm(past, sampler, B, sample_id_base=gid0, first_steps=nsteps)
+        x, _ = model._generate_ddpm(past, sampler, hi - lo, sample_id_base=lo, first_steps=nsteps)
         return x
 
     def sync():
@@ -144,27 +237,29 @@ def main():
 
     if a.warmup > 0:
         run(a.warmup)
-    sync()
-    t0 = time.perf_counter()
-    x = run(a.steps)
-    if dist is not None:
-        xg = x if backend == "nccl" else x.cpu()
-        gathered = [torch.empty_like(xg) for _ in range(world)]
-        dist.all_gather(gathered, xg)  # the trivial gather of the sharded result (RCCL over xGMI)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    times = []
+    for _ in range(max(1, a.repeats)):
+        sync()
+        t0 = time.perf_counter()
+        x = run(steps)
+        if dist is not None:   # the trivial gather of the sharded result (RCCL over xGMI); gloo rehearsal stages through the host
+            cdist.gather_samples(x if backend == "nccl" else x.cpu(), gb, rank, world)
+        sync()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        times.append(el)
+    elapsed = float(np.median(times))
 
-    # ---- roofline of the dominant kernel: a profiled re-run of the same K steps ------
+    # ---- roofline of the dominant kernel class: a profiled re-run of the same K steps ------
     roofline = None
     if not a.no_profile and rank == 0:
         L = native.lib()
         h = model.denoiser._handle
         native.check(L.cm_profile_enable(h, 1))
-        run(a.steps)
+        run(steps)
         torch.cuda.synchronize()
         ms = (C.c_float * 8)()
         cnt = (C.c_int64 * 8)()
@@ -177,45 +272,56 @@ def main():
         native.check(L.cm_profile_enable(h, 0))
         fl = C.c_double()
         by = C.c_double()
-        native.check(L.cm_model_cost(h, B, C.byref(fl), C.byref(by)))
-        conv3_flops = model.denoiser.conv3_flops(B) * a.steps
+        nb = hi - lo
+        native.check(L.cm_model_cost(h, nb, C.byref(fl), C.byref(by)))
+        conv3_flops = model.denoiser.conv3_flops(nb) * steps
+        conv3_exec = model.denoiser.conv3_exec_flops(nb) * steps
         conv_s = ms[0] / 1e3
         ach = conv3_flops / conv_s / 1e12 if conv_s > 0 else 0.0
+        exe = conv3_exec / conv_s / 1e12 if conv_s > 0 else 0.0
+        peak = FP32_MFMA_PEAK_TFLOPS if a.dtype == "f32" else F16_MFMA_PEAK_TFLOPS
         roofline = {
-            "kernel": "conv_mfma_kernel<*,*,27|8|0> -- all 3x3x3 conv launches (implicit GEMM, v_mfma_f32_32x32x2_f32)",
-            "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": hbm_traffic(),
+            "kernel": "all 3x3x3 conv launches: conv_wino_kernel (Winograd F(2x2,3x3) over the in-plane axes, full- and "
+                      "half-resolution layers), conv_mfma_kernel<*,*,27|8> (direct / parity-form upsample / stride 2 / "
+                      "K-split quarter resolution), conv_first_kernel, conv_smalln_kernel",
+            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+            "frac": ach / peak, "traffic": hbm_traffic(),
+            "executed_tflops": exe, "executed_frac": exe / peak,
             "launches": int(cnt[0]), "avg_launch_us": ms[0] * 1e3 / max(1, cnt[0]),
-            "measured_with": "second run of the same K steps, same launch configuration, with HIP events around every "
-                             "launch on its launch stream (events inside the timed run would add ~1.5 us per "
-                             "launch to `value`); rocprofv3 --kernel-trace --stats of this command: "
-                             "profiles/round1_kernel_stats.csv",
+            "measured_with": "an extra run of the same K steps, same launch configuration, with HIP events around every "
+                             "launch on its launch stream (events inside the timed runs would add ~1.5 us per launch to "
+                             "`value`); `achieved` counts ALGORITHMIC FLOPs (2 x 27 x Ci x Co per voxel, as PyTorch counts "
+                             "the reference's nn.Conv3d), `executed_*` the matrix-core FLOPs actually issued (Winograd and "
+                             "parity forms issue fewer): frac > executed_frac is the algorithmic saving; rocprofv3 "
+                             "--kernel-trace --stats of this command: profiles/round2_kernel_stats.csv",
             "algorithmic_gflop_per_launch": conv3_flops / max(1, cnt[0]) / 1e9,
-            "class_ms_per_step": {k: ms[i] / a.steps for i, k in enumerate(
-                ["conv3x3x3", "conv1x1x1_gemm", "groupnorm_stats", "attention_core", "elementwise"]) },
+            "class_ms_per_step": {k: ms[i] / steps for i, k in enumerate(
+                ["conv3x3x3", "conv1x1x1_gemm", "groupnorm_stats", "attention_block", "elementwise"])},
             "step_algorithmic_gflop": fl.value / 1e9, "step_algorithmic_gbytes": by.value / 1e9,
         }
     if dist is not None:
         dist.barrier()
 
     cpu = None
-    if rank == 0 and world == 1 and a.cpu_budget > 0:
+    if rank == 0 and world == 1 and a.cpu_budget > 0 and a.dtype == "f32" and not a.grid:
         cpu = cpu_baseline(res, Cn, B, a.cpu_budget)
 
     if rank == 0:
+        wl = "config/ATC.yml sampling (BASELINE configs[1])" if not a.grid and a.dtype == "f32" else \
+            "config/ATC.yml UNet on the %s grid, %s matrix-core operands (BASELINE configs[4] shape)" % (a.grid or "12x36", a.dtype)
         out = {
             "metric": "denoise-steps/sec (UNet fwd + sampler update) at ATC [B,4,T,H,W]",
-            "value": world * a.steps / elapsed,
+            "value": world * steps / elapsed,
             "unit": "denoise-steps/s (each over a batch of %d chains)" % B,
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3,
+            "n_gpus": world, "steps": steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "repeat_ms_per_step": [t / steps * 1e3 for t in times],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "sample_steps_per_s": world * B * a.steps / elapsed,
-            "config": {"workload": "config/ATC.yml sampling (BASELINE configs[1]): DDPM p_sample_loop, T=1000, "
-                                   "batch %d per GPU, UNet base 32 mult [1,2,4]" % B,
+            "dtype": a.dtype, "data": "synthetic",
+            "sample_steps_per_s": world * B * steps / elapsed,
+            "config": {"workload": wl + ": DDPM p_sample_loop, T=%d, batch %d per GPU, UNet base 32 mult [1,2,4]" % (res.timesteps, B),
                        "channels": Cn, "grid": [res.rows, res.cols], "past_len": res.past_len,
-                       "future_len": res.future_len, "global_batch": world * B, "parallelism": "batch-shard x%d" % world},
+                       "future_len": res.future_len, "global_batch": gb, "parallelism": "batch-shard x%d" % world},
         }
         if roofline:
             out["roofline"] = roofline

@@ -28,6 +28,8 @@ namespace cm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
@@ -35,12 +37,17 @@ __device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_r
 // (rows beyond ROWS are padding).  Where the patch grid is not a multiple of PY / PX the LAST tile of a row is
 // shifted back inside the grid; it recomputes a few patches of its neighbour but owns (stores, counts in the
 // statistics) only its own ones -- a.ntx / a.nty tiles of step PX / PY patches.
-template <int BZ, int PY, int PX, int OCC>
+// F16 (reduced-precision plan, BASELINE configs[4]; the reference trains under fp16 autocast, ddpm.py:116-120): the
+// transformed inputs are rounded to f16 when they are written to LDS (row = 16 channels = 32 B + 16 B pad), the
+// transformed weights arrive as f16, and ONE v_mfma_f32_32x32x16_f16 per (z tap, component) contracts the whole
+// 16-channel chunk with fp32 accumulation -- 1/16 of the matrix-pipe time of the 8 fp32 instructions it replaces.
+// GroupNorm / SiLU, the transforms, the epilogue and the GroupNorm statistics stay fp32.
+template <int BZ, int PY, int PX, int OCC, bool F16>
 __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
   constexpr int NP = PY * PX, ROWS = BZ * NP;
   static_assert(ROWS <= 32 && ROWS > 16, "one (partly filled) 32-row accumulator block per frequency component");
   constexpr int HZ = BZ + 2, UR = HZ * NP;      // input planes, rows per component in LDS
-  constexpr int CS = 16, S = CS + 4;            // channel chunk, LDS row stride (conflict-free b128 for consecutive rows)
+  constexpr int CS = 16, S = F16 ? 12 : CS + 4;  // channel chunk, LDS row stride in dwords (conflict-free b128 for consecutive rows)
   constexpr int NITEMS = HZ * NP * (CS / 4);    // staging items: (plane, patch, channel quad)
   static_assert(NITEMS <= 256, "one staging item per thread");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
         okmask |= (ok ? 1u : 0u) << (i * 4 + j);
       }
   }
-  float *const uw = U + (size_t)(zi * NP + patch) * S + 4 * quad;   // + xi * UR * S per component
+  float *const uw = U + (size_t)(zi * NP + patch) * S + (F16 ? 2 : 4) * quad;   // + xi * UR * S per component
 
   f32x16 acc[4];
 #pragma unroll
@@ -100,9 +107,15 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
 
   const int n0 = a.C0 >> 4, nchunks = n0 + (a.C1 >> 4);
   const int Ctot = a.C0 + a.C1;
-  // packed weights: [n tile][chunk][wave = xi_y][group g = dz * 2 + k8][xi_x][lane] float4
-  const f32x4 *wbase = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * nchunks * (4 * 24 * 64) + wave * (24 * 64) + lane;
-  f32x4 bq[2][4];
+  // packed weights: [n tile][chunk][wave = xi_y][group g][xi_x][lane] 16 bytes per lane:
+  //   fp32: g = dz * 2 + k8 (6 groups), 4 floats  ci = 8*k8 + 4*hh + jj;   f16: g = dz (3 groups), 8 halves  ci = 8*hh + j
+  constexpr int NG = F16 ? 3 : 6;
+  const f32x4 *wbase = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * nchunks * (4 * NG * 4 * 64) + wave * (NG * 4 * 64) + lane;
+  // register ring of weight groups: slot of group g is g % RS, the next group (possibly the next chunk's first) is
+  // prefetched into slot (g + 1) % RS -- RS must divide NG so that a chunk always starts on slot 0
+  constexpr int RS = F16 ? 3 : 2;
+  static_assert(NG % RS == 0, "ring slots must line up at chunk boundaries");
+  f32x4 bq[RS][4];
 #pragma unroll
   for (int x = 0; x < 4; ++x) bq[0][x] = wbase[x * 64];
 
@@ -150,30 +163,43 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
     __syncthreads();                        // previous chunk's fragments have been read
     if (stager) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4 *>(uw + (size_t)k * UR * S) = d[k];   // component xi = i * 4 + j = k
+      for (int k = 0; k < 16; ++k) {                                   // component xi = i * 4 + j = k
+        if constexpr (F16) {
+          const f16x4 hv = {(_Float16)d[k][0], (_Float16)d[k][1], (_Float16)d[k][2], (_Float16)d[k][3]};
+          *reinterpret_cast<f16x4 *>(uw + (size_t)k * UR * S) = hv;
+        } else {
+          *reinterpret_cast<f32x4 *>(uw + (size_t)k * UR * S) = d[k];
+        }
+      }
     }
     __syncthreads();
-    // ---- matrix phase: 6 groups (z tap, 8-channel half) x 4 components ------------------------------
+    // ---- matrix phase: NG groups (z tap [, 8-channel half]) x 4 components ---------------------------------
 #pragma unroll
-    for (int g = 0; g < 6; ++g) {
-      const int dz = g >> 1, k8 = g & 1;
+    for (int g = 0; g < NG; ++g) {
+      const int dz = F16 ? g : g >> 1, k8 = F16 ? 0 : g & 1;
       // refill the other ring slot with the next group (possibly the next chunk's first)
       {
-        const bool more = g < 5 || ch + 1 < nchunks;
-        const f32x4 *wn = wbase + (size_t)(g < 5 ? ch : ch + 1) * (4 * 24 * 64) + (size_t)(g < 5 ? g + 1 : 0) * (4 * 64);
+        const bool more = g < NG - 1 || ch + 1 < nchunks;
+        const f32x4 *wn = wbase + (size_t)(g < NG - 1 ? ch : ch + 1) * (4 * NG * 4 * 64) + (size_t)(g < NG - 1 ? g + 1 : 0) * (4 * 64);
         if (more) {
 #pragma unroll
-          for (int x = 0; x < 4; ++x) bq[(g + 1) & 1][x] = wn[x * 64];
+          for (int x = 0; x < 4; ++x) bq[(g + 1) % RS][x] = wn[x * 64];
         }
       }
       f32x4 af[4];
 #pragma unroll
       for (int x = 0; x < 4; ++x) af[x] = *reinterpret_cast<const f32x4 *>(arow + (size_t)x * UR * S + (size_t)dz * NP * S + 8 * k8);
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
+      if constexpr (F16) {
 #pragma unroll
         for (int x = 0; x < 4; ++x)
-          acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x][jj], bq[g & 1][x][jj], acc[x], 0, 0, 0);
+          acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[x]), __builtin_bit_cast(f16x8, bq[g % RS][x]), acc[x], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int x = 0; x < 4; ++x)
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x][jj], bq[g % RS][x][jj], acc[x], 0, 0, 0);
+      }
     }
   }
 
@@ -319,7 +345,7 @@ bool conv_wino_pick(int Zo, int Yo, int Xo, int *bz, int *by, int *bx) {
   return best >= 0.6;
 }
 
-size_t conv_wino_lds(int bz, int by, int bx) {
+size_t conv_wino_lds(int bz, int by, int bx) {   // sized for the fp32 image (the f16 one is smaller)
   const size_t ur = (size_t)(bz + 2) * (by / 2) * (bx / 2);
   const size_t u = 16 * ur * 20, x = 4 * 2 * 16 * 64;
   return (128 + (u > x ? u : x)) * sizeof(float);
@@ -332,7 +358,7 @@ bool conv_wino_ok(const ConvArgs &a) {
          a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo && conv_wino_lds(a.bz, a.by, a.bx) <= 80 * 1024;
 }
 
-hipError_t launch_conv_wino(const ConvArgs &a_in, hipStream_t st) {
+hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
   ConvArgs a = a_in;
   a.dbg = conv_dbg_flags();
   if (!conv_wino_ok(a)) return hipErrorInvalidValue;
@@ -344,12 +370,16 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, hipStream_t st) {
     int dev = 0;                                                                                    \
     (void)hipGetDevice(&dev);                                                                       \
     if (!attr_set[dev & 63]) {                                                                      \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<z, py, px, 2>), \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<z, py, px, 2, false>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+      if (e == hipSuccess)                                                                          \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<z, py, px, 2, true>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
       if (e != hipSuccess) return e;                                                                \
       attr_set[dev & 63] = true;                                                                    \
     }                                                                                               \
-    hipLaunchKernelGGL((conv_wino_kernel<z, py, px, 2>), grid, dim3(256), lds, st, a);              \
+    if (f16) hipLaunchKernelGGL((conv_wino_kernel<z, py, px, 2, true>), grid, dim3(256), lds, st, a);   \
+    else hipLaunchKernelGGL((conv_wino_kernel<z, py, px, 2, false>), grid, dim3(256), lds, st, a);  \
     return hipGetLastError();                                                                       \
   }
   CM_WINO_TILES(X)

@@ -105,6 +105,7 @@ struct Op {
   bool skip_if_fused = false;  // this op is the stand-alone skip conv that a later op absorbs
   bool wino = false;        // Winograd F(2x2,3x3) kernel (cm_conv_wino.hip): full-resolution stride-1 3x3x3 layers
   float *d_wwino = nullptr;
+  float *d_wwino16 = nullptr;   // the same weights as f16 operands (reduced-precision plan, cm_model_set_precision)
   bool first_k = false;     // the UNet's first conv on its dedicated kernel (cm_conv_io.hip)
   int first_cin = 4;        //   input channels it contracts per tap: 4 (C <= 4) or 8
   float *d_wfirst = nullptr;
@@ -161,6 +162,7 @@ struct cm_model {
   std::vector<BlockDesc> enc, bott, dec;
   int final_ch = 0;
   bool finalized = false;
+  int precision = CM_PRECISION_F32;   // matrix-core operand type of the Winograd layers (inference plan)
 
   std::vector<void *> allocs;
   std::vector<std::unique_ptr<Act>> acts;
@@ -430,6 +432,53 @@ void pack_wino(const std::vector<float> *wi, const std::vector<int> *ii, int Co,
           }
 }
 
+// IEEE binary16 bits of a float (round to nearest even; overflow -> infinity, like a device cast)
+uint16_t f32_to_f16_bits(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  const int32_t exp = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+  uint32_t man = x & 0x7fffffu;
+  if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
+  if (exp >= 31) return (uint16_t)(sign | 0x7c00u);
+  if (exp <= 0) {
+    if (exp < -10) return (uint16_t)sign;
+    man |= 0x800000u;
+    const int shift = 14 - exp;
+    uint32_t h = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (h & 1))) ++h;
+    return (uint16_t)(sign | h);
+  }
+  uint32_t h = ((uint32_t)exp << 10) | (man >> 13);
+  const uint32_t rem = man & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;
+  return (uint16_t)(sign | h);
+}
+
+// f16 packing of the Winograd weights (cm_conv_wino.hip, F16): [n tile][chunk][xi_y][dz][xi_x][lane][8 halves],
+// lane = 32*hh + co % 32, ci = chunk*16 + 8*hh + j.  Returned as floats holding two halves each (upload helper).
+std::vector<float> pack_wino_f16(const std::vector<float> &wi, int Co, int Ci, int Ci_pad) {
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  const int ntn = (Co + 31) / 32, nch = Ci_pad / 16;
+  std::vector<uint16_t> out((size_t)ntn * nch * 4 * 3 * 4 * 64 * 8, 0);
+  for (int co = 0; co < Co; ++co)
+    for (int ci = 0; ci < Ci; ++ci)
+      for (int dz = 0; dz < 3; ++dz)
+        for (int xy = 0; xy < 4; ++xy)
+          for (int xx = 0; xx < 4; ++xx) {
+            const int nt = co / 32, r = co % 32, chunk = ci / 16, hh = (ci % 16) / 8, j = ci % 8;
+            double acc = 0;
+            for (int dy = 0; dy < 3; ++dy)
+              for (int dx = 0; dx < 3; ++dx) acc += G[xy][dy] * G[xx][dx] * (double)wi[((size_t)co * Ci + ci) * 27 + (dz * 3 + dy) * 3 + dx];
+            const size_t o = (((((((size_t)nt * nch + chunk) * 4 + xy) * 3 + dz) * 4 + xx) * 64) + hh * 32 + r) * 8 + j;
+            out[o] = f32_to_f16_bits((float)acc);
+          }
+  std::vector<float> packed(out.size() / 2);
+  std::memcpy(packed.data(), out.data(), out.size() * 2);
+  return packed;
+}
+
 int pick_ck(int C0, int C1) {
   for (int ck : {32, 16, 8})
     if (C0 % ck == 0 && C1 % ck == 0) return ck;
@@ -655,6 +704,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     std::vector<float> ww;
     pack_wino(&wi, nullptr, s.Co, Ci_ref, Ci_pad, &ww, nullptr, nullptr);
     if (upload(m, ww, &op.d_wwino)) return 1;
+    if (m->precision == CM_PRECISION_F16 && upload(m, pack_wino_f16(wi, s.Co, Ci_ref, Ci_pad), &op.d_wwino16)) return 1;
   }
   // the UNet's first conv (C <= 8 data channels -> base): dedicated kernel, whole weight set in registers
   if (s.s0 == m->x8_act && s.ntaps == 27 && s.stride == 1 && !s.ups && !s.gn && !s.temb && !s.resid && !s.s1 &&
@@ -1051,8 +1101,10 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     op.stat_act->nslots = cb.nslots;
     CM_HIP(cm::launch_ksplit_combine(cb, st));
   } else if (op.wino) {
-    ca.wfrag = op.d_wwino;
-    CM_HIP(cm::launch_conv_wino(ca, st));
+    // reduced-precision plan: f16 operands in the inference forward; the training forward stays fp32
+    const bool f16 = op.d_wwino16 && !m->train_fwd;
+    ca.wfrag = f16 ? op.d_wwino16 : op.d_wwino;
+    CM_HIP(cm::launch_conv_wino(ca, f16, st));
   } else if (op.first_k) {
     CM_HIP(cm::launch_conv_first(ca, op.first_cin, op.d_wfirst, st));
   } else if (op.small_n) {
@@ -1368,6 +1420,14 @@ int cm_model_get_param(const cm_model *m, const char *name, float *h_data, int64
   const Param &p = m->params[it->second];
   if (numel != p.numel()) return fail("size mismatch for %s", name);
   std::memcpy(h_data, p.host.data(), (size_t)numel * sizeof(float));
+  return 0;
+}
+
+int cm_model_set_precision(cm_model *m, int32_t precision) {
+  if (!m) return fail("null model handle");
+  if (m->finalized) return fail("precision must be chosen before cm_model_finalize");
+  if (precision != CM_PRECISION_F32 && precision != CM_PRECISION_F16) return fail("unknown precision %d", precision);
+  m->precision = precision;
   return 0;
 }
 
@@ -1929,6 +1989,33 @@ int cm_debug_time_conv(cm_model *m, int32_t index, int32_t MB, int32_t bz, int32
     CM_HIP(hipMemcpy(op.d_mtab, mt.data(), mt.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   return rc;
+}
+
+// Matrix-core FLOPs the plan actually EXECUTES per kernel class (<= the algorithmic count: the parity form of the
+// upsample convs runs 8 of 27 taps, the Winograd layers 16 multiplies per 2x2 outputs and z tap instead of 36,
+// computed on whole 32-row blocks and shifted tiles; padding rows of partly filled tiles are counted as executed).
+int cm_model_exec_flops(const cm_model *m, int32_t B, double flops[8]) {
+  if (!m || !m->finalized || !flops) return fail("model not finalized");
+  for (int i = 0; i < 8; ++i) flops[i] = 0;
+  for (const Op &op : m->ops) {
+    if (op.kind == OP_ATTN) { flops[op.cls] += 4.0 * op.S * (double)op.S * op.E * B; continue; }
+    if (op.kind != OP_CONV || op.skip_if_fused) continue;
+    const cm::ConvArgs &a = op.ca;
+    const double Ci = a.C0 + a.C1;
+    double f = op.flops_per_sample;
+    if (op.wino) {
+      int bz = 0, by = 0, bx = 0;
+      if (cm::conv_wino_pick(a.Zo, a.Yo, a.Xo, &bz, &by, &bx)) {
+        const double tiles = (double)(a.Zo / bz) * ((a.Yo + by - 1) / by) * ((a.Xo + bx - 1) / bx);
+        f = tiles * ((a.Co + 31) / 32) * 16.0 * 32 * 32 * Ci * 3 * 2;
+        if (op.d_s2w) f += tiles * ((a.Co + 31) / 32) * 4.0 * 32 * 32 * (op.skip0->C + (op.skip1 ? op.skip1->C : 0)) * 2;
+      }
+    } else if (a.par) {
+      f = op.flops_per_sample * 8.0 / 27.0;
+    }
+    flops[op.cls] += f * B;
+  }
+  return 0;
 }
 
 int cm_model_class_flops(const cm_model *m, int32_t B, double flops[8]) {

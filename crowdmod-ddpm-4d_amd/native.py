@@ -43,6 +43,7 @@ class cm_sample_opts(C.Structure):
 
 
 SAMPLER_DDPM, SAMPLER_DDIM, SAMPLER_FM_EULER = 0, 1, 2
+PRECISION_F32, PRECISION_F16 = 0, 1
 GUIDANCE_NONE, GUIDANCE_SPARSITY = 0, 1
 TABLES = ("beta", "alpha", "alpha_bar", "sqrt_alpha_bar", "one_by_sqrt_alpha", "sqrt_one_minus_alpha_bar")
 
@@ -67,6 +68,7 @@ SIGNATURES = {
     "cm_model_param_info": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "cm_model_set_param": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     "cm_model_get_param": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "cm_model_set_precision": (C.c_int, [_P, C.c_int32]),
     "cm_model_finalize": (C.c_int, [_P]),
     "cm_unet_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P]),
     "cm_unet_forward_host": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
@@ -87,6 +89,7 @@ SIGNATURES = {
     "cm_profile_report": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "cm_model_cost": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cm_model_class_flops": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double)]),
+    "cm_model_exec_flops": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double)]),
     "cm_frame_metrics": (C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "cm_debug_conv_flags": (C.c_int, [C.c_int32]),
     "cm_debug_conv_count": (C.c_int, [_P, C.POINTER(C.c_int32)]),

@@ -44,6 +44,17 @@ class UNet:
                                                                perturb_norm=False)
         self._handle = None
         self._geom = None
+        self.precision = "f32"
+
+    def set_precision(self, precision: str):
+        """'f32' (default, exact) or 'f16': f16 matrix-core operands with fp32 accumulation in the Winograd 3x3x3
+        layers of the inference plan -- the counterpart of the reference's torch.amp.autocast (ddpm.py:116-120)."""
+        if precision not in ("f32", "f16"):
+            raise ValueError(f"precision {precision!r}: 'f32' or 'f16'")
+        if precision != self.precision:
+            self._release()
+            self.precision = precision
+        return self
 
     # -- nn.Module surface ---------------------------------------------------------
     def eval(self):
@@ -129,6 +140,8 @@ class UNet:
         h = C.c_void_p()
         native.check(L.cm_model_create(C.byref(c), C.byref(h)))
         try:
+            if self.precision == "f16":
+                native.check(L.cm_model_set_precision(h, native.PRECISION_F16))
             for name, arr in self._params.items():
                 arr = np.ascontiguousarray(arr, dtype=np.float32)
                 native.check(L.cm_model_set_param(h, name.encode(), arr.ctypes.data, arr.size))
@@ -394,6 +407,12 @@ class UNet:
         f, b = C.c_double(), C.c_double()
         native.check(native.lib().cm_model_cost(self._handle, B, C.byref(f), C.byref(b)))
         return f.value, b.value
+
+    def conv3_exec_flops(self, B: int) -> float:
+        """Matrix-core FLOPs the 3x3x3 convolutions actually execute (Winograd / parity forms run fewer)."""
+        fl = (C.c_double * 8)()
+        native.check(native.lib().cm_model_exec_flops(self._handle, B, fl))
+        return float(fl[0])
 
     def conv3_flops(self, B: int) -> float:
         """Algorithmic FLOPs of the 3x3x3 convolutions of one forward at batch B."""

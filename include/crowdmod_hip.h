@@ -79,6 +79,13 @@ int cm_model_param_info(const cm_model *m, int32_t index, const char **name, int
 /* load_state_dict(): ddpm.py:161,288.  `numel` must match the tensor's size. */
 int cm_model_set_param(cm_model *m, const char *name, const float *h_data, int64_t numel);
 int cm_model_get_param(const cm_model *m, const char *name, float *h_data, int64_t numel);
+/* Matrix-core operand type of the inference plan, chosen before cm_model_finalize.  CM_PRECISION_F32 (default):
+ * exact fp32 everywhere.  CM_PRECISION_F16: the Winograd 3x3x3 layers (every stride-1 3x3x3 conv with an even
+ * in-plane grid: 71-98 % of the FLOPs) contract f16 operands with fp32 accumulation (v_mfma_f32_32x32x16_f16);
+ * GroupNorm statistics, SiLU, residuals, attention and the sampler update stay fp32.  The reference's analogue is
+ * torch.amp.autocast around the denoiser (models/diffusion/ddpm.py:116-120).  Tolerance: tests/test_gpu_f16.py. */
+enum { CM_PRECISION_F32 = 0, CM_PRECISION_F16 = 1 };
+int cm_model_set_precision(cm_model *m, int32_t precision);
 /* Packs weights into MFMA fragment order and precomputes the time-embedding
  * tables; must be called after the last cm_model_set_param and before any
  * forward.  Fails if a tensor was never set. */
@@ -197,6 +204,9 @@ int cm_profile_report(cm_model *m, char *buf, int64_t capacity);
 int cm_model_cost(const cm_model *m, int32_t B, double *flops, double *bytes);
 /* Algorithmic FLOPs of one forward per kernel class (same indices as cm_profile_read). */
 int cm_model_class_flops(const cm_model *m, int32_t B, double flops[8]);
+/* Matrix-core FLOPs the plan EXECUTES per class (parity-form upsample convs: 8 of 27 taps; Winograd F(2x2,3x3)
+ * layers: 16 multiplies per 2x2 outputs and z tap instead of 36) -- the hardware-utilisation side of the roofline. */
+int cm_model_exec_flops(const cm_model *m, int32_t B, double flops[8]);
 
 /* ---- sampling metrics: the per-frame reductions of utils/metrics/metricsGenerator.py:70-92,
  * 120-186,293-339 (PSNR, masked PSNR, relative density error, total variation) on the device.
