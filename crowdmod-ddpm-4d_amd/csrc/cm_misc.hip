@@ -486,7 +486,9 @@ __global__ __launch_bounds__(256) void attn_core_kernel(const float *__restrict_
   __syncthreads();
   const float scale = rsqrtf((float)D);
   const int part = tid % PARTS, rl = tid / PARTS;
-  for (int row0 = 0; row0 < S; row0 += ROWS) {
+  // gridDim.z > 1 (many tokens): workgroup z handles the query-row passes z, z + gridDim.z, ... so that the
+  // S^2 work of one (head, sample) spreads over several CUs (each re-stages K / V: 2 * S * D floats)
+  for (int row0 = blockIdx.z * ROWS; row0 < S; row0 += ROWS * gridDim.z) {
     const int row = row0 + rl;
     const int rowc = row < S ? row : S - 1;  // surplus lanes shadow the last row (shuffles stay convergent)
     const float *qp = base + (size_t)rowc * 3 * E + hd * D + 8 * part;
@@ -534,7 +536,9 @@ hipError_t launch_attn_core(const float *qkv, float *out, int B, int S, int E, i
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_core_kernel<DD>),                \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);             \
     if (e != hipSuccess) return e;                                                                          \
-    hipLaunchKernelGGL((attn_core_kernel<DD>), dim3(heads, B), dim3(256), smem, st, qkv, out, S, E);          \
+    const int rows_per_pass = 256 / (DD / 8);                                                              \
+    const int nz = S > 2 * rows_per_pass ? (S + rows_per_pass - 1) / rows_per_pass : 1;                     \
+    hipLaunchKernelGGL((attn_core_kernel<DD>), dim3(heads, B, nz), dim3(256), smem, st, qkv, out, S, E);     \
     return hipGetLastError();                                                                               \
   }
   CM_ATTN(8) CM_ATTN(16) CM_ATTN(32) CM_ATTN(64)
