@@ -203,6 +203,8 @@ hipError_t launch_wgrad(const ConvArgs &a, int MB, const float *dy, int dy_cs, f
                         hipStream_t st);
 hipError_t launch_wgrad_reduce(const float *part, int G, int ncb, int nkb, int ntaps, int Co, int Ci, float *dW,
                                hipStream_t st);
+// parity-form (upsample conv) partials [G * 8 parities][ncb][nkb][8][32][32] -> dW [Co][Ci][27] in reference layout
+hipError_t launch_wgrad_reduce_par(const float *part, int G, int ncb, int nkb, int Co, int Ci, float *dW, hipStream_t st);
 hipError_t launch_voxel_sum(const float *x, int B, int V, int C, int cs, float *out, int ostride,
                             float *scratch /* [16][B][ostride] */, hipStream_t st);
 hipError_t launch_batch_sum(const float *in, int B, int C, int stride, float *out, int accumulate, hipStream_t st);

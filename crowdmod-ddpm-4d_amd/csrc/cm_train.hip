@@ -29,7 +29,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int g = blockIdx.x, cb = blockIdx.y, kb = blockIdx.z;
+  // parity form of an upsample conv (a.par): blockIdx.x = tile group * 8 + parity class; the class (pz,py,px) reads
+  // dY at the output voxels 2i + p and the LOW-resolution input at i + e + p - 1, e in {0,1}^3 (the forward's own
+  // 2x2x2 form, cm_conv.hip) -- 8 taps instead of 27 on the materialised upsampled tensor: 3.4x fewer FLOPs
+  const int par = a.par ? (int)(blockIdx.x & 7) : 0;
+  const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1, os = a.par ? 2 : 1;
+  const int g = a.par ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, cb = blockIdx.y, kb = blockIdx.z;
   const int td = a.td, pad = (td == 3) ? 1 : 0;
   const int HZ = (a.bz - 1) * a.stride + td, HY = (a.by - 1) * a.stride + td, HX = (a.bx - 1) * a.stride + td;
   const int HV = HZ * HY * HX;
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
       int off = -1;
       const int pk = m < nbox ? a.mtab[m] : -1;
       if (pk >= 0) {
-        const int oz = z0 + ((pk >> 18) & 255), oy = y0 + ((pk >> 9) & 511), ox = x0 + (pk & 511);
+        const int oz = os * (z0 + ((pk >> 18) & 255)) + pz, oy = os * (y0 + ((pk >> 9) & 511)) + py, ox = os * (x0 + (pk & 511)) + px;
         if (oz < a.Zo && oy < a.Yo && ox < a.Xo) off = ((b * a.Zo + oz) * a.Yo + oy) * a.Xo + ox;
       }
       rowoff[m] = off;
@@ -101,7 +106,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
       *reinterpret_cast<f32x4 *>(&dyt[m * 32 + 4 * q]) = v;
     }
     // input halo (same transform as the forward staging)
-    const int cz0 = z0 * a.stride - pad, cy0 = y0 * a.stride - pad, cx0 = x0 * a.stride - pad;
+    const int cz0 = z0 * a.stride + (a.par ? pz - 1 : -pad), cy0 = y0 * a.stride + (a.par ? py - 1 : -pad),
+              cx0 = x0 * a.stride + (a.par ? px - 1 : -pad);
     for (int i = tid; i < HV * 8; i += 256) {
       const int hv = i >> 3, q = i & 7;
       const int pk = a.hvtab[hv];
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
   for (int ti = 0; ti < TW; ++ti) {
     const int t = wave + 4 * ti;
     if (t < ntaps) {
-      float *p = part + ((((size_t)g * gridDim.y + cb) * gridDim.z + kb) * ntaps + t) * 1024;
+      float *p = part + ((((size_t)blockIdx.x * gridDim.y + cb) * gridDim.z + kb) * ntaps + t) * 1024;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int co = (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
 
 hipError_t launch_wgrad(const ConvArgs &a, int MB, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb,
                         hipStream_t st) {
-  if (a.bs != 1 || a.par) return hipErrorInvalidValue;
+  if (a.bs != 1 || (a.par && (a.td != 2 || a.ntaps != 8 || a.stride != 1 || a.ups))) return hipErrorInvalidValue;
   const int HV = ((a.bz - 1) * a.stride + a.td) * ((a.by - 1) * a.stride + a.td) * ((a.bx - 1) * a.stride + a.td);
   const int TM = 32 * MB;
   const size_t lds = ((size_t)2 * TM + (size_t)TM * 32 + (size_t)HV * 32) * 4;
@@ -166,7 +172,43 @@ hipError_t launch_wgrad(const ConvArgs &a, int MB, const float *dy, int dy_cs, f
     if (e != hipSuccess) return e;
     attr_set[dev & 63] = true;
   }
-  hipLaunchKernelGGL(wgrad_kernel, dim3(G, ncb, nkb), dim3(256), lds, st, a, dy, dy_cs, part, G);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(a.par ? G * 8 : G, ncb, nkb), dim3(256), lds, st, a, dy, dy_cs, part, G);
+  return hipGetLastError();
+}
+
+// Parity-form partials part[g * 8 + p][cb][kb][e (8)][32 co][32 ci] -> dW[co][ci][27 taps] (reference layout):
+// the forward's parity weights are W_p[e] = sum of the taps d that land on source offset e for parity p, so
+// dW[d] = sum_p dW_p[e(p, d)]  with  e = emap(p_axis, d_axis) per axis:  p = 0: d0 -> 0, d1,d2 -> 1;  p = 1: d0,d1 -> 0, d2 -> 1.
+__global__ __launch_bounds__(256) void wgrad_reduce_par_kernel(const float *__restrict__ part, int G, int ncb, int nkb, int Co, int Ci,
+                                                               float *__restrict__ dW) {
+  const long long n = (long long)ncb * nkb * 27 * 1024;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int cil = (int)(i & 31), col = (int)((i >> 5) & 31);
+  long long q = i >> 10;
+  const int d = (int)(q % 27); q /= 27;
+  const int kb = (int)(q % nkb);
+  const int cb = (int)(q / nkb);
+  const int co = cb * 32 + col, ci = kb * 32 + cil;
+  if (co >= Co || ci >= Ci) return;
+  const int dz = d / 9, dy = (d / 3) % 3, dx = d % 3;
+  const long long per_gp = (long long)ncb * nkb * 8 * 1024;
+  float s = 0.f;
+  for (int g = 0; g < G; ++g)
+    for (int p = 0; p < 8; ++p) {
+      const int pz = (p >> 2) & 1, py = (p >> 1) & 1, px = p & 1;
+      const int ez = pz == 0 ? (dz == 0 ? 0 : 1) : (dz == 2 ? 1 : 0);
+      const int ey = py == 0 ? (dy == 0 ? 0 : 1) : (dy == 2 ? 1 : 0);
+      const int ex = px == 0 ? (dx == 0 ? 0 : 1) : (dx == 2 ? 1 : 0);
+      const int e = (ez * 2 + ey) * 2 + ex;
+      s += part[(size_t)(g * 8 + p) * per_gp + ((((size_t)cb * nkb + kb) * 8 + e) << 10) + col * 32 + cil];
+    }
+  dW[((size_t)co * Ci + ci) * 27 + (dy * 3 + dx) * 3 + dz] = s;
+}
+
+hipError_t launch_wgrad_reduce_par(const float *part, int G, int ncb, int nkb, int Co, int Ci, float *dW, hipStream_t st) {
+  const long long n = (long long)ncb * nkb * 27 * 1024;
+  hipLaunchKernelGGL(wgrad_reduce_par_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, G, ncb, nkb, Co, Ci, dW);
   return hipGetLastError();
 }
 
