@@ -49,7 +49,7 @@ for k in sorted(fetch, key=lambda k: -sum(fetch[k]["FETCH_SIZE"])):
     lds_conf = tot("SQ_LDS_BANK_CONFLICT") / max(1.0, tot("SQ_LDS_IDX_ACTIVE")) if s else float("nan")
     rows.append((k, n, fk, wk, hbm, mfma_busy, valu_per_mfma, lds_conf))
     m3 = re.search(r"conv_mfma_kernel<\d+, \d+, (\d+)", k)
-    if (m3 and m3.group(1) in ("27", "127", "8")) or "conv_smalln" in k:
+    if (m3 and m3.group(1) in ("27", "127", "8")) or "conv_smalln" in k or "conv_wino_kernel" in k or "conv_first_kernel" in k:
         conv_bytes += hbm * n
         conv_n += n
 with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.csv"), "w") as fo:
@@ -57,8 +57,11 @@ with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.csv"), "w") as fo:
              "mfma_busy_frac,valu_per_mfma,lds_bank_conflict_share\n")
     for r in rows:
         fo.write('"%s",%d,%.1f,%.1f,%.0f,%.3f,%.2f,%.3f\n' % r)
+sys.path.insert(0, ROOT)
+from bench import csrc_sha16  # noqa: E402  (fingerprint of the kernel sources this measurement belongs to)
 json.dump({
-    "kernel_class": "conv_mfma_kernel<*,*,27|127|8> + conv_smalln_kernel (all 3x3x3 conv launches)",
+    "kernel_class": "conv_wino_kernel + conv_mfma_kernel<*,*,27|127|8> + conv_first_kernel + conv_smalln_kernel (all 3x3x3 conv launches)",
+    "csrc_sha16": csrc_sha16(),
     "hbm_bytes_per_launch": conv_bytes / max(1, conv_n),
     "launches_counted": conv_n,
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh); bytes = "
