@@ -42,17 +42,28 @@ __device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_r
 // transformed weights arrive as f16, and ONE v_mfma_f32_32x32x16_f16 per (z tap, component) contracts the whole
 // 16-channel chunk with fp32 accumulation -- 1/16 of the matrix-pipe time of the 8 fp32 instructions it replaces.
 // GroupNorm / SiLU, the transforms, the epilogue and the GroupNorm statistics stay fp32.
-template <int BZ, int PY, int PX, int OCC, bool F16>
+// TWO (the 8 x 2 x 2 full-resolution tile, where it fits next to U at two workgroups per CU): staging in two steps --
+// (A) every halo voxel is normalised / activated ONCE into an LDS image R, its global loads issued before the
+// previous chunk's matrix phase so that they complete under it; (B) the items transform their 4x4 patches out of R.
+// The one-step form evaluates GroupNorm + SiLU per patch, i.e. 1.78x per voxel (patches overlap), and the kernel is
+// vector-issue bound (10 vector instructions per MFMA, profiles/round2_pmc_summary.csv).  With TWO the fp32 U image is
+// unpadded with an XOR swizzle of the 16-byte column by (row >> 2) instead of 4 pad dwords per row.
+template <int BZ, int PY, int PX, int OCC, bool F16, bool TWO>
 __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
   constexpr int NP = PY * PX, ROWS = BZ * NP;
   static_assert(ROWS <= 32 && ROWS > 16, "one (partly filled) 32-row accumulator block per frequency component");
   constexpr int HZ = BZ + 2, UR = HZ * NP;      // input planes, rows per component in LDS
-  constexpr int CS = 16, S = F16 ? 12 : CS + 4;  // channel chunk, LDS row stride in dwords (conflict-free b128 for consecutive rows)
+  constexpr bool SWZ = TWO && !F16;              // unpadded fp32 rows, 16-byte column XOR-swizzled by (row >> 2) & 3
+  static_assert(!SWZ || NP == 4, "the swizzle key of a z tap is (row >> 2) + dz");
+  constexpr int CS = 16, S = F16 ? 12 : (SWZ ? CS : CS + 4);  // channel chunk, LDS row stride in dwords (conflict-free b128 for consecutive rows)
+  constexpr int RYH = 2 * PY + 2, RXH = 2 * PX + 2, RV = HZ * RYH * RXH, RS_ = 24;   // activated halo image R[RV][24] (TWO)
+  constexpr int RK = (RV * 4 + 255) / 256;       // step-A rounds per thread
   constexpr int NITEMS = HZ * NP * (CS / 4);    // staging items: (plane, patch, channel quad)
   static_assert(NITEMS <= 256, "one staging item per thread");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int *outoff = reinterpret_cast<int *>(lds);   // [4 sub-blocks (a, b)][32 rows] output voxel index or -1
   float *U = lds + 128;                         // [16][UR][S]; later the exchange buffer [4 waves][2][16][64]
+  float *R = U + 16 * UR * S;                   // TWO: [RV][24] normalised + activated halo of the current chunk
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,7 +108,25 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
         okmask |= (ok ? 1u : 0u) << (i * 4 + j);
       }
   }
-  float *const uw = U + (size_t)(zi * NP + patch) * S + (F16 ? 2 : 4) * quad;   // + xi * UR * S per component
+  const int urow = zi * NP + patch;
+  float *const uw = U + (size_t)urow * S + (F16 ? 2 : 4) * (SWZ ? (quad ^ ((urow >> 2) & 3)) : quad);   // + xi * UR * S per component
+  // TWO, step A: voxel (tid >> 2) + 64 k of the halo box, channel quad tid & 3
+  int asoff[RK];
+  unsigned aok = 0;
+  if constexpr (TWO) {
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+      const int v = (tid >> 2) + 64 * k;
+      const int vz = v / (RYH * RXH), rem = v - vz * (RYH * RXH), vy = rem / RXH, vx = rem - vy * RXH;
+      const int cz = z0 - 1 + vz, cy = y0 - 1 + vy, cx = x0 - 1 + vx;
+      const bool ok = v < RV && b0 < a.B && cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs;
+      asoff[k] = ok ? ((bs * a.Zs + cz) * a.Ys + cy) * a.Xs + cx : 0;
+      aok |= (ok ? 1u : 0u) << k;
+    }
+  }
+  const int aq = tid & 3;
+  // TWO, step B: R offset of the item's patch origin (plane zi, rows 2py.., cols 2px..)
+  const int rbase = ((zi * RYH + 2 * (patch / PX)) * RXH + 2 * (patch % PX)) * RS_ + 4 * quad;
 
   f32x16 acc[4];
 #pragma unroll
@@ -119,7 +148,14 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
   for (int x = 0; x < 4; ++x) bq[0][x] = wbase[x * 64];
 
-  const float *arow = U + (size_t)(wave * 4) * UR * S + (size_t)min(r, ROWS - 1) * S + 4 * hh;   // component xi_y = wave, xi_x = 0, tap 0
+  const int ar = min(r, ROWS - 1);
+  const float *arow = U + (size_t)(wave * 4) * UR * S + (size_t)ar * S + (SWZ ? 0 : 4 * hh);   // component xi_y = wave, xi_x = 0, tap 0
+  f32x4 ald[RK];                                 // TWO: step-A loads of the NEXT chunk, in flight during the matrix phase
+  if constexpr (TWO) {
+    const float *sp0 = a.src0 + 4 * aq;          // chunk 0 always comes from src0
+#pragma unroll
+    for (int k = 0; k < RK; ++k) ald[k] = *reinterpret_cast<const f32x4 *>(sp0 + (size_t)asoff[k] * a.C0);
+  }
 
   for (int ch = 0; ch < nchunks; ++ch) {
     const float *src;
@@ -128,26 +164,40 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
     else { src = a.src1; Cs = a.C1; c0 = (ch - n0) * CS; cg0 = a.C0 + c0; }
     // ---- stage + input transform ---------------------------------------------------------------------
     f32x4 d[16];
-    const float *sp = src + c0 + 4 * quad;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] = *reinterpret_cast<const f32x4 *>(sp + (size_t)soff[k] * Cs);
     f32x4 sc1 = {1.f, 1.f, 1.f, 1.f}, sh1 = {0.f, 0.f, 0.f, 0.f}, pm1 = {1.f, 1.f, 1.f, 1.f};
+    const int gq = TWO ? aq : quad;               // channel quad this thread normalises
     if (a.gn) {
-      const float *g = a.gn + (size_t)bs * 2 * Ctot + cg0 + 4 * quad;
+      const float *g = a.gn + (size_t)bs * 2 * Ctot + cg0 + 4 * gq;
       sc1 = *reinterpret_cast<const f32x4 *>(g);
       sh1 = *reinterpret_cast<const f32x4 *>(g + Ctot);
     }
-    if (a.pm) pm1 = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)bs * a.pm_stride + cg0 + 4 * quad);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      f32x4 w = d[k];
+    if (a.pm) pm1 = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)bs * a.pm_stride + cg0 + 4 * gq);
+    auto activate = [&](f32x4 w, bool ok) -> f32x4 {
       if (a.gn) {
         w = w * sc1 + sh1;
         if (a.silu) { w[0] = silu_w(w[0]); w[1] = silu_w(w[1]); w[2] = silu_w(w[2]); w[3] = silu_w(w[3]); }
       }
       if (a.pm) w = w * pm1;
-      if (!((okmask >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding of the ACTIVATED tensor
-      d[k] = w;
+      return ok ? w : f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding of the ACTIVATED tensor
+    };
+    if constexpr (TWO) {
+      // step A: this chunk's halo voxels (loaded during the previous matrix phase) -> activated image R
+#pragma unroll
+      for (int k = 0; k < RK; ++k) {
+        const int v = (tid >> 2) + 64 * k;
+        if (v < RV) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = activate(ald[k], (aok >> k) & 1u);
+      }
+      __syncthreads();                        // R complete; every wave is past the previous chunk's matrix phase
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[i * 4 + j] = *reinterpret_cast<const f32x4 *>(R + rbase + (i * RXH + j) * RS_);
+    } else {
+      const float *sp = src + c0 + 4 * quad;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) d[k] = *reinterpret_cast<const f32x4 *>(sp + (size_t)soff[k] * Cs);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) d[k] = activate(d[k], (okmask >> k) & 1u);
     }
     // B^T d B: rows of B^T = (1,0,-1,0), (0,1,1,0), (0,-1,1,0), (0,1,0,-1); first along x (index j), then y (i)
 #pragma unroll
@@ -160,7 +210,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
       const f32x4 e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j], e3 = d[3 * 4 + j];
       d[0 * 4 + j] = e0 - e2; d[1 * 4 + j] = e1 + e2; d[2 * 4 + j] = e2 - e1; d[3 * 4 + j] = e1 - e3;
     }
-    __syncthreads();                        // previous chunk's fragments have been read
+    if constexpr (!TWO) __syncthreads();    // previous chunk's fragments have been read
     if (stager) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) {                                   // component xi = i * 4 + j = k
@@ -173,6 +223,15 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
       }
     }
     __syncthreads();
+    if constexpr (TWO) {                      // next chunk's halo loads: in flight under this chunk's matrix phase
+      if (ch + 1 < nchunks) {
+        const int cn = ch + 1;
+        const float *spn = (cn < n0 ? a.src0 + cn * CS : a.src1 + (cn - n0) * CS) + 4 * aq;
+        const int Cn = cn < n0 ? a.C0 : a.C1;
+#pragma unroll
+        for (int k = 0; k < RK; ++k) ald[k] = *reinterpret_cast<const f32x4 *>(spn + (size_t)asoff[k] * Cn);
+      }
+    }
     // ---- matrix phase: NG groups (z tap [, 8-channel half]) x 4 components ---------------------------------
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -187,8 +246,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
         }
       }
       f32x4 af[4];
+      const int acol = SWZ ? 4 * ((2 * k8 + hh) ^ (((ar >> 2) + dz) & 3)) : 8 * k8;   // swizzled 16-byte column of row ar + dz * NP
 #pragma unroll
-      for (int x = 0; x < 4; ++x) af[x] = *reinterpret_cast<const f32x4 *>(arow + (size_t)x * UR * S + (size_t)dz * NP * S + 8 * k8);
+      for (int x = 0; x < 4; ++x) af[x] = *reinterpret_cast<const f32x4 *>(arow + (size_t)x * UR * S + (size_t)dz * NP * S + acol);
       if constexpr (F16) {
 #pragma unroll
         for (int x = 0; x < 4; ++x)
@@ -345,17 +405,22 @@ bool conv_wino_pick(int Zo, int Yo, int Xo, int *bz, int *by, int *bx) {
   return best >= 0.6;
 }
 
-size_t conv_wino_lds(int bz, int by, int bx) {   // sized for the fp32 image (the f16 one is smaller)
+bool conv_wino_two_step(int bz, int by, int bx) { return bz == 8 && by == 4 && bx == 4; }
+
+size_t conv_wino_lds(int bz, int by, int bx, bool f16) {
   const size_t ur = (size_t)(bz + 2) * (by / 2) * (bx / 2);
-  const size_t u = 16 * ur * 20, x = 4 * 2 * 16 * 64;
-  return (128 + (u > x ? u : x)) * sizeof(float);
+  const bool two = conv_wino_two_step(bz, by, bx);
+  const size_t u = 16 * ur * (f16 ? 12 : (two ? 16 : 20));
+  const size_t rimg = two ? (size_t)(bz + 2) * (by + 2) * (bx + 2) * 24 : 0;
+  const size_t x = 4 * 2 * 16 * 64;               // exchange buffer of the output transform (overlays U and R)
+  return (128 + (u + rimg > x ? u + rimg : x)) * sizeof(float);
 }
 
 bool conv_wino_ok(const ConvArgs &a) {
   return a.ntaps == 27 && a.td == 3 && a.stride == 1 && !a.par && !a.ups && a.ks <= 1 && a.bs == 1 && (!a.s2w || (a.s2C0 % 32 == 0 && a.s2C1 % 32 == 0)) &&
          a.C0 % 16 == 0 && a.C1 % 16 == 0 && conv_wino_tile_ok(a.bz, a.by, a.bx) && a.Zo % a.bz == 0 && a.Yo % 2 == 0 && a.Xo % 2 == 0 &&
          a.by <= a.Yo && a.bx <= a.Xo && a.nty == (a.Yo + a.by - 1) / a.by && a.ntx == (a.Xo + a.bx - 1) / a.bx && a.ntz == a.Zo / a.bz &&
-         a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo && conv_wino_lds(a.bz, a.by, a.bx) <= 80 * 1024;
+         a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo && conv_wino_lds(a.bz, a.by, a.bx, false) <= 80 * 1024;
 }
 
 hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
@@ -363,23 +428,24 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
   a.dbg = conv_dbg_flags();
   if (!conv_wino_ok(a)) return hipErrorInvalidValue;
   const dim3 grid((unsigned)(a.B * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + 31) / 32));
-  const size_t lds = conv_wino_lds(a.bz, a.by, a.bx);
+  const size_t lds = conv_wino_lds(a.bz, a.by, a.bx, f16);
 #define X(z, py, px)                                                                                \
   if (a.bz == z && a.by == 2 * py && a.bx == 2 * px) {                                              \
     static bool attr_set[64] = {false};                                                             \
     int dev = 0;                                                                                    \
     (void)hipGetDevice(&dev);                                                                       \
     if (!attr_set[dev & 63]) {                                                                      \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<z, py, px, 2, false>), \
+      constexpr bool two = (z == 8 && py == 2 && px == 2);                                          \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<z, py, px, 2, false, two>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
       if (e == hipSuccess)                                                                          \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<z, py, px, 2, true>), \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<z, py, px, 2, true, two>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
       if (e != hipSuccess) return e;                                                                \
       attr_set[dev & 63] = true;                                                                    \
     }                                                                                               \
-    if (f16) hipLaunchKernelGGL((conv_wino_kernel<z, py, px, 2, true>), grid, dim3(256), lds, st, a);   \
-    else hipLaunchKernelGGL((conv_wino_kernel<z, py, px, 2, false>), grid, dim3(256), lds, st, a);  \
+    if (f16) hipLaunchKernelGGL((conv_wino_kernel<z, py, px, 2, true, (z == 8 && py == 2 && px == 2)>), grid, dim3(256), lds, st, a);   \
+    else hipLaunchKernelGGL((conv_wino_kernel<z, py, px, 2, false, (z == 8 && py == 2 && px == 2)>), grid, dim3(256), lds, st, a);  \
     return hipGetLastError();                                                                       \
   }
   CM_WINO_TILES(X)

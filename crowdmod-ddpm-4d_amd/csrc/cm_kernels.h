@@ -99,7 +99,7 @@ hipError_t launch_conv_first(const ConvArgs &a, int cin, const float *wpk, hipSt
 // [64 lanes][4] transformed weights; statistics slots per tile: 4 (the (a, b) sub-blocks).
 bool conv_wino_tile_ok(int bz, int by, int bx);
 bool conv_wino_ok(const ConvArgs &a);
-size_t conv_wino_lds(int bz, int by, int bx);
+size_t conv_wino_lds(int bz, int by, int bx, bool f16);
 // f16: a.wfrag holds the f16 packing (3 groups per chunk and wave, 8 halves per lane): fp32 accumulate, f16 operands
 hipError_t launch_conv_wino(const ConvArgs &a, bool f16, hipStream_t st);
 // tile (bz, by, bx) the Winograd kernel would use for an output grid, or false if none of its shapes fits
