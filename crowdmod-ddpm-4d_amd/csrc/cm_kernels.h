@@ -102,6 +102,9 @@ bool conv_wino_ok(const ConvArgs &a);
 size_t conv_wino_lds(int bz, int by, int bx, bool f16);
 // f16: a.wfrag holds the f16 packing (3 groups per chunk and wave, 8 halves per lane): fp32 accumulate, f16 operands
 hipError_t launch_conv_wino(const ConvArgs &a, bool f16, hipStream_t st);
+// Weight gradient in the Winograd domain (same tiles): partials part[G][ncb][nkb][3][16][32 ci][32 co], then G^T dU G
+hipError_t launch_wgrad_wino(const ConvArgs &a, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb, hipStream_t st);
+hipError_t launch_wgrad_wino_reduce(const float *part, int G, int ncb, int nkb, int Co, int Ci, float *dW, hipStream_t st);
 // tile (bz, by, bx) the Winograd kernel would use for an output grid, or false if none of its shapes fits
 bool conv_wino_pick(int Zo, int Yo, int Xo, int *bz, int *by, int *bx);
 
