@@ -65,10 +65,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
+  // 1x1x1 convs have a single tap: the four waves then split the voxel pairs of a tile instead (wave w takes pairs
+  // w, w + 4, ...) and write four pseudo-tap partials that the reduce pass sums -- otherwise three waves idle
+  const bool vsplit = ntaps == 1 && !(a.dbg & 8192);
   int tapoff[TW];
 #pragma unroll
   for (int ti = 0; ti < TW; ++ti) {
-    const int t = min(wave + 4 * ti, ntaps - 1);
+    const int t = vsplit ? 0 : min(wave + 4 * ti, ntaps - 1);
     const int dz = t / (td * td), rem = t - dz * td * td, dyy = rem / td, dx = rem - dyy * td;
     tapoff[ti] = ((dz * HY + dyy) * HX + dx) * 32;
   }
@@ -130,6 +133,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
     __syncthreads();
     // voxel pairs outermost, the wave's taps innermost: one dy value and one halo index feed up to
     // seven independent accumulators, so the LDS reads of a pair are issued together
+    if (vsplit) {
+#pragma unroll 4
+      for (int m0 = 2 * wave; m0 < TM; m0 += 8) {
+        const float av = dyt[(m0 + h) * 32 + r];
+        const float bv0 = at[rowhv[m0 + h] * 32 + r];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv0, acc[0], 0, 0, 0);
+      }
+      continue;
+    }
 #pragma unroll 2
     for (int m0 = 0; m0 < TM; m0 += 2) {
       const float av = dyt[(m0 + h) * 32 + r];
@@ -141,6 +153,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
       for (int ti = 0; ti < TW; ++ti)
         if (wave + 4 * ti < ntaps) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[ti], acc[ti], 0, 0, 0);
     }
+  }
+  if (vsplit) {   // pseudo-tap = wave: part[g][cb][kb][4][32][32]
+    float *p = part + ((((size_t)blockIdx.x * gridDim.y + cb) * gridDim.z + kb) * 4 + wave) * 1024;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int co = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      p[co * 32 + r] = acc[0][reg];
+    }
+    return;
   }
 #pragma unroll
   for (int ti = 0; ti < TW; ++ti) {
@@ -172,7 +193,9 @@ hipError_t launch_wgrad(const ConvArgs &a, int MB, const float *dy, int dy_cs, f
     if (e != hipSuccess) return e;
     attr_set[dev & 63] = true;
   }
-  hipLaunchKernelGGL(wgrad_kernel, dim3(a.par ? G * 8 : G, ncb, nkb), dim3(256), lds, st, a, dy, dy_cs, part, G);
+  ConvArgs aa = a;
+  aa.dbg = conv_dbg_flags();
+  hipLaunchKernelGGL(wgrad_kernel, dim3(a.par ? G * 8 : G, ncb, nkb), dim3(256), lds, st, aa, dy, dy_cs, part, G);
   return hipGetLastError();
 }
 
@@ -216,7 +239,21 @@ hipError_t launch_wgrad_reduce_par(const float *part, int G, int ncb, int nkb, i
 // [Co][Ci][kH][kW][kL] (internal tap (dz,dy,dx) = reference [kH=dy][kW=dx][kL=dz]); 1 tap -> [Co][Ci].
 // Threads walk the PARTIAL layout (ci fastest) so the G reads per output are coalesced.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int G, int ncb, int nkb,
-                                                           int ntaps, int Co, int Ci, float *__restrict__ dW) {
+                                                           int ntaps, int Co, int Ci, float *__restrict__ dW, int nvs) {
+  if (ntaps == 1 && nvs == 4) {   // 1x1x1: the kernel wrote four pseudo-tap (per-wave) partials per group
+    const long long n1 = (long long)ncb * nkb * 1024;
+    const long long i1 = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i1 >= n1) return;
+    const int cil1 = (int)(i1 & 31), col1 = (int)((i1 >> 5) & 31);
+    const long long blk = i1 >> 10;
+    const int co1 = (int)(blk / nkb) * 32 + col1, ci1 = (int)(blk % nkb) * 32 + cil1;
+    if (co1 >= Co || ci1 >= Ci) return;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g)
+      for (int w = 0; w < 4; ++w) s += part[((size_t)g * ncb * nkb + blk) * 4096 + (size_t)w * 1024 + col1 * 32 + cil1];
+    dW[(size_t)co1 * Ci + ci1] = s;
+    return;
+  }
   const long long per_g = (long long)ncb * nkb * ntaps * 1024;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= per_g) return;
@@ -244,8 +281,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 hipError_t launch_wgrad_reduce(const float *part, int G, int ncb, int nkb, int ntaps, int Co, int Ci, float *dW,
                                hipStream_t st) {
   const long long total = (long long)ncb * nkb * ntaps * 1024;
+  const int nvs = (ntaps == 1 && !(conv_dbg_flags() & 8192)) ? 4 : 1;   // per-wave partials of the 1x1x1 voxel split
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, G, ncb, nkb,
-                     ntaps, Co, Ci, dW);
+                     ntaps, Co, Ci, dW, nvs);
   return hipGetLastError();
 }
 
