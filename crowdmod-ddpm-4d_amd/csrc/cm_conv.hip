@@ -30,6 +30,8 @@ namespace cm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division sequence
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -50,6 +52,11 @@ template <int MB, int NB, int FAST, int BZ = 0, int BY = 0, int BX = 0, int STR 
 __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPEC_OCC : 2))) void conv_mfma_kernel(const ConvArgs a) {
   constexpr bool SPEC = BZ != 0;
   constexpr bool SPAR = SPEC && (FAST % 100) == 8;   // specialised parity form: 2 taps per dimension
+  // FAST >= 200 (reduced-precision plan, parity form only): the staged tile is rounded to f16 (row = 32 channels
+  // = 64 B + 8 B pad), the weights arrive as f16, and a wave's 8-channel slice of a tap is ONE
+  // v_mfma_f32_32x32x8_f16 (fp32 accumulate) instead of four fp32 instructions
+  constexpr bool F16 = FAST >= 200;
+  static_assert(!F16 || SPAR, "f16 operands are instantiated for the specialised parity form only");
   constexpr int STD = SPAR ? 2 : 3;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TM = 32 * MB;
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
   const int HV1 = HZ * HY * HX;
   const int HV = a_bs * HV1;
   const int HVp = (HV + 3) & ~3;
-  const int S = (SPEC ? 32 : a.CK) + 4;
+  const int S = F16 ? 18 : (SPEC ? 32 : a.CK) + 4;   // LDS row stride in dwords
   const int nbox = a_bs * a_bz * a_by * a_bx;
   // packed row / halo coordinates: host tables in general, arithmetic (constant divisors) when specialised
   auto mtab_at = [&](int m) -> int {
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
     const int pk = pk_ab[mb] >= 0 ? pk_ab[mb] : 0;
     const int x = pk & 511, y = (pk >> 9) & 511, z = (pk >> 18) & 255, s = pk >> 26;
     const int hv = ((s * HZ + z * a_stride) * HY + y * a_stride) * HX + x * a_stride;
-    abase[mb] = hv * S + 4 * h;
+    abase[mb] = hv * S + (F16 ? 2 : 4) * h;
   }
 
   f32x16 acc[MB][NB];
@@ -199,12 +206,25 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
   f32x4 bq[PD][NB];
   const f32x4 *wrun = wtile + ((size_t)(ch0 * TAPS + PD) * 4 + wave) * NB * 64;  // next ring refill
   int wleft = (ch1 - ch0) * TAPS - PD;                                            // refills still to issue
-  if constexpr (fast) {
+  // f16 operands: the same stream with 8-byte fragments (4 halves per lane and step)
+  f32x2 bq2[PD][NB];
+  const f32x2 *wtile2 = reinterpret_cast<const f32x2 *>(a.wfrag + (size_t)par * a.wpar_stride) +
+                        (size_t)nt * nchunks * nsteps * NB * 64 + lane;
+  const f32x2 *wrun2 = wtile2 + ((size_t)(ch0 * TAPS + PD) * 4 + wave) * NB * 64;
+  if constexpr (fast && !F16) {
 #pragma unroll
     for (int d = 0; d < PD; ++d) {
       const f32x4 *wp = wtile + ((size_t)ch0 * (TAPS * 4) + (wave + 4 * d)) * NB * 64;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) bq[d][nb] = wp[nb * 64];
+    }
+  }
+  if constexpr (F16) {
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      const f32x2 *wp = wtile2 + ((size_t)ch0 * (TAPS * 4) + (wave + 4 * d)) * NB * 64;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bq2[d][nb] = wp[nb * 64];
     }
   }
 
@@ -309,7 +329,14 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
           }
           if (a.pm) w = w * pm1;
           if (!((okmask >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (slot_mine(k)) *reinterpret_cast<f32x4 *>(&A[hv * S + 4 * q4]) = w;
+          if (slot_mine(k)) {
+            if constexpr (F16) {
+              const f16x4 hw = {(_Float16)w[0], (_Float16)w[1], (_Float16)w[2], (_Float16)w[3]};
+              *reinterpret_cast<f16x4 *>(&A[hv * S + 2 * q4]) = hw;
+            } else {
+              *reinterpret_cast<f32x4 *>(&A[hv * S + 4 * q4]) = w;
+            }
+          }
         }
       }
     }
@@ -378,10 +405,14 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
       constexpr int TD = (TAPS == 27) ? 3 : 2;
       static_assert(PD == TD, "the unrolled taps must be the dx steps of one kernel row");
       const int step_x = S, step_y = (HX - (TD - 1)) * S, step_z = ((HY - (TD - 1)) * HX - (TD - 1)) * S;
-      int aoff = wave * 8, dyc = 0;
+      int aoff = wave * (F16 ? 4 : 8), dyc = 0;
       f32x4 afn[MB];
+      f32x2 afn2[MB];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) afn[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + aoff]);
+      for (int mb = 0; mb < MB; ++mb) {
+        if constexpr (F16) afn2[mb] = *reinterpret_cast<const f32x2 *>(&A[abase[mb] + aoff]);
+        else afn[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + aoff]);
+      }
 #pragma unroll 1
       for (int i0 = 0; i0 < TAPS; i0 += PD) {
         const int step_row = (i0 + PD >= TAPS) ? 0 : (dyc == TD - 1 ? step_z : step_y);  // (the last tap re-reads itself)
@@ -389,24 +420,43 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
 #pragma unroll
         for (int d = 0; d < PD; ++d) {
           f32x4 af[MB];
+          f32x2 af2[MB];
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) af[mb] = afn[mb];
+          for (int mb = 0; mb < MB; ++mb) { af[mb] = afn[mb]; af2[mb] = afn2[mb]; }
           aoff += (d < PD - 1) ? step_x : step_row;
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) afn[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + aoff]);
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
+          for (int mb = 0; mb < MB; ++mb) {
+            if constexpr (F16) afn2[mb] = *reinterpret_cast<const f32x2 *>(&A[abase[mb] + aoff]);
+            else afn[mb] = *reinterpret_cast<const f32x4 *>(&A[abase[mb] + aoff]);
+          }
+          if constexpr (F16) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
               for (int nb = 0; nb < NB; ++nb)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mb][jj], bq[d][nb][jj], acc[mb][nb], 0, 0, 0);
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(f16x4, af2[mb]), __builtin_bit_cast(f16x4, bq2[d][nb]),
+                                                                   acc[mb][nb], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+              for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                  acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mb][jj], bq[d][nb][jj], acc[mb][nb], 0, 0, 0);
+          }
           // refill this ring slot with the fragments PD taps ahead (possibly next chunk): the stream
           // of one wave is linear in (chunk, tap), so a running pointer and a countdown suffice
           if (wleft > 0) {
+            if constexpr (F16) {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bq[d][nb] = wrun[nb * 64];
-            wrun += 4 * NB * 64;
+              for (int nb = 0; nb < NB; ++nb) bq2[d][nb] = wrun2[nb * 64];
+              wrun2 += 4 * NB * 64;
+            } else {
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb) bq[d][nb] = wrun[nb * 64];
+              wrun += 4 * NB * 64;
+            }
             --wleft;
           }
         }
@@ -653,6 +703,11 @@ void conv_build_tables(const ConvArgs &a, int MB, int *hvtab, int *mtab) {
   X(1, 2) X(2, 2) X(3, 2) X(4, 2) \
   X(1, 4) X(2, 4)
 
+bool conv_par_f16_variant(int MB, int NB, int bz, int by, int bx) {
+  return (MB == 5 && NB == 1 && bz == 4 && by == 6 && bx == 6) || (MB == 2 && NB == 2 && bz == 2 && by == 3 && bx == 9) ||
+         (MB == 3 && NB == 1 && bz == 2 && by == 7 && bx == 6) || (MB == 2 && NB == 2 && bz == 4 && by == 4 && bx == 4);
+}
+
 bool conv_variant_exists(int MB, int NB) {
 #define X(m, n) if (MB == m && NB == n) return true;
   CM_CONV_VARIANTS(X)
@@ -703,6 +758,7 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
   dim3 grid((unsigned)(a.nts * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + TN - 1) / TN),
             a.par ? 8u : (a.ks > 1 ? (unsigned)a.ks : 1u));
   const int fastk = (a.CK == 32 && (a.ntaps == 27 || a.ntaps == 8)) ? a.ntaps : 0;
+  if (a.f16 && !(fastk == 8 && a.bs == 1 && a.stride == 1 && a.par && !a.ups && a.td == 2)) return hipErrorInvalidValue;
 #define CM_LAUNCH_T(KERNEL, m, n, f)                                                             \
   {                                                                                              \
     static bool attr_set[64] = {false};                                                          \
@@ -748,8 +804,10 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
   const bool specpar = fastk == 8 && a.bs == 1 && a.stride == 1 && a.par && !a.ups && a.td == 2 && !(dbg & 2048);
   const bool specs2 = fastk == 27 && a.bs == 1 && a.stride == 2 && !a.par && !a.ups && a.td == 3 && !a.s2w && !(dbg & 2048);
 #define CM_SPEC_PAR(m, n, z, y, x)                                                 \
-  if (specpar && MB == m && NB == n && a.bz == z && a.by == y && a.bx == x)        \
-    CM_LAUNCH_T((conv_mfma_kernel<m, n, 8, z, y, x>), m, n, 8)
+  if (specpar && MB == m && NB == n && a.bz == z && a.by == y && a.bx == x) {      \
+    if (a.f16) CM_LAUNCH_T((conv_mfma_kernel<m, n, 208, z, y, x>), m, n, 208)      \
+    CM_LAUNCH_T((conv_mfma_kernel<m, n, 8, z, y, x>), m, n, 8)                     \
+  }
 #define CM_SPEC_S2(m, n, z, y, x)                                                  \
   if (specs2 && MB == m && NB == n && a.bz == z && a.by == y && a.bx == x)         \
     CM_LAUNCH_T((conv_mfma_kernel<m, n, 27, z, y, x, 2>), m, n, 27)

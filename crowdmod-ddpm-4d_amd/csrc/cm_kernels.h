@@ -66,7 +66,10 @@ struct ConvArgs {
   int dbg;             // ablation switches for performance studies (0 in production)
   float *dbg_buf;      // cycle-stamp sink of the diagnostic build paths
   int stagger;         // start delay (in 64-cycle units) applied to every other first-wave workgroup
+  int f16;             // 1: wfrag holds f16 fragments (4 halves per lane and step); specialised parity form only
 };
+// does launch_conv have an f16-operand instantiation for this parity-form tile?
+bool conv_par_f16_variant(int MB, int NB, int bz, int by, int bx);
 
 // Diagnostic switches of the conv kernels (ConvArgs::dbg): CM_CONV_DBG from the environment, or the value
 // set through cm_debug_conv_flags (>= 0) -- tests flip the XCD tile remap inside one process with it.

@@ -106,6 +106,8 @@ struct Op {
   bool wino = false;        // Winograd F(2x2,3x3) kernel (cm_conv_wino.hip): full-resolution stride-1 3x3x3 layers
   float *d_wwino = nullptr;
   float *d_wwino16 = nullptr;   // the same weights as f16 operands (reduced-precision plan, cm_model_set_precision)
+  float *d_wfrag16 = nullptr;   // f16 fragments of a parity-form upsample conv (reduced-precision plan)
+  long long wpar_stride16 = 0;
   bool first_k = false;     // the UNet's first conv on its dedicated kernel (cm_conv_io.hip)
   int first_cin = 4;        //   input channels it contracts per tap: 4 (C <= 4) or 8
   float *d_wfirst = nullptr;
@@ -379,6 +381,30 @@ std::vector<float> parity_weights(const std::vector<float> &Wi, int Co, int Ci) 
     }
   }
   return out;
+}
+
+uint16_t f32_to_f16_bits(float f);
+
+// f16 version of pack_conv_weights (same order, 4 halves per lane and step), returned as floats holding two halves each
+std::vector<float> pack_conv_weights_f16(const float *W, int Co, int Ci, int ntaps, int Ci_pad, int CK, int NB) {
+  const int TN = 32 * NB, ntn = (Co + TN - 1) / TN, nch = Ci_pad / CK, K8 = CK / 8, nsteps = ntaps * K8;
+  std::vector<uint16_t> out((size_t)ntn * nch * nsteps * NB * 64 * 4, 0);
+  size_t o = 0;
+  for (int nt = 0; nt < ntn; ++nt)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int s = 0; s < nsteps; ++s) {
+        const int t = s / K8, j = s % K8;
+        for (int nb = 0; nb < NB; ++nb)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int jj = 0; jj < 4; ++jj, ++o) {
+              const int co = nt * TN + nb * 32 + (lane & 31);
+              const int ci = ch * CK + 8 * j + 4 * (lane >> 5) + jj;
+              if (co < Co && ci < Ci) out[o] = f32_to_f16_bits(W[((size_t)co * Ci + ci) * ntaps + t]);
+            }
+      }
+  std::vector<float> packed(out.size() / 2);
+  std::memcpy(packed.data(), out.data(), out.size() * 2);
+  return packed;
 }
 
 std::vector<float> pack_conv_weights(const float *W, int Co, int Ci, int ntaps, int Ci_pad, int CK, int NB) {
@@ -680,6 +706,15 @@ int add_conv(cm_model *m, const ConvSpec &s) {
       std::vector<float> one = pack_conv_weights(wp.data() + p8 * per, (int)w.shape[0], Ci_ref, 8, Ci_pad, a.CK, op.NB);
       a.wpar_stride = (long long)one.size();
       wf.insert(wf.end(), one.begin(), one.end());
+    }
+    if (m->precision == CM_PRECISION_F16 && a.CK == 32) {   // reduced-precision plan: the same fragments as f16
+      std::vector<float> wf16;
+      for (int p8 = 0; p8 < 8; ++p8) {
+        std::vector<float> one = pack_conv_weights_f16(wp.data() + p8 * per, (int)w.shape[0], Ci_ref, 8, Ci_pad, a.CK, op.NB);
+        op.wpar_stride16 = (long long)one.size();
+        wf16.insert(wf16.end(), one.begin(), one.end());
+      }
+      if (upload(m, wf16, &op.d_wfrag16)) return 1;
     }
   } else {
     wf = pack_conv_weights(wi.data(), (int)w.shape[0], Ci_ref, s.ntaps, Ci_pad, a.CK, op.NB);
@@ -1110,6 +1145,9 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   } else if (op.small_n) {
     CM_HIP(cm::launch_conv_smalln(ca, op.MB, op.d_wsmall, st));
   } else {
+    if (op.d_wfrag16 && !m->train_fwd && cm::conv_par_f16_variant(op.MB, op.NB, ca.bz, ca.by, ca.bx)) {
+      ca.wfrag = op.d_wfrag16; ca.wpar_stride = op.wpar_stride16; ca.f16 = 1;   // f16 operands, fp32 accumulate
+    }
     CM_HIP(cm::launch_conv(ca, op.MB, op.NB, st));
   }
   return 0;

@@ -16,7 +16,7 @@ for f in glob.glob("$OUT/p*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, c in agg.items():
-    if "conv_mfma" not in k and "conv_first" not in k and "smalln" not in k and "attn_head" not in k: continue
+    if not any(s in k for s in ("conv_mfma", "conv_wino", "conv_first", "smalln", "attn_head", "wgrad")): continue
     n = len(next(iter(c.values())))
     if n < 10: continue
     print(k, "dispatches", n)
