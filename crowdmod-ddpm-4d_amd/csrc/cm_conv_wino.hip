@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
   constexpr bool SWZ = TWO && !F16;              // unpadded fp32 rows, 16-byte column XOR-swizzled by (row >> 2) & 3
   static_assert(!SWZ || NP == 4, "the swizzle key of a z tap is (row >> 2) + dz");
   constexpr int CS = 16, S = F16 ? 12 : (SWZ ? CS : CS + 4);  // channel chunk, LDS row stride in dwords (conflict-free b128 for consecutive rows)
-  constexpr int RYH = 2 * PY + 2, RXH = 2 * PX + 2, RV = HZ * RYH * RXH, RS_ = 24;   // activated halo image R[RV][24] (TWO)
+  constexpr int RYH = 2 * PY + 2, RXH = 2 * PX + 2, RV = HZ * RYH * RXH, RS_ = BZ == 8 ? 24 : 20;   // activated halo image R[RV][24] (TWO)
   constexpr int RK = (RV * 4 + 255) / 256;       // step-A rounds per thread
   constexpr int NITEMS = HZ * NP * (CS / 4);    // staging items: (plane, patch, channel quad)
   static_assert(NITEMS <= 256, "one staging item per thread");
@@ -405,13 +405,15 @@ bool conv_wino_pick(int Zo, int Yo, int Xo, int *bz, int *by, int *bx) {
   return best >= 0.6;
 }
 
-bool conv_wino_two_step(int bz, int by, int bx) { return bz == 8 && by == 4 && bx == 4; }
+// two-step staging where the activated halo image fits next to U at two workgroups per CU: the full-resolution tile,
+// and every tile of the f16 plan (its U image is 40 % smaller)
+bool conv_wino_two_step(int bz, int by, int bx, bool f16) { return (bz == 8 && by == 4 && bx == 4) || f16; }
 
 size_t conv_wino_lds(int bz, int by, int bx, bool f16) {
   const size_t ur = (size_t)(bz + 2) * (by / 2) * (bx / 2);
-  const bool two = conv_wino_two_step(bz, by, bx);
+  const bool two = conv_wino_two_step(bz, by, bx, f16);
   const size_t u = 16 * ur * (f16 ? 12 : (two ? 16 : 20));
-  const size_t rimg = two ? (size_t)(bz + 2) * (by + 2) * (bx + 2) * 24 : 0;
+  const size_t rimg = two ? (size_t)(bz + 2) * (by + 2) * (bx + 2) * (bz == 8 ? 24 : 20) : 0;
   const size_t x = 4 * 2 * 16 * 64;               // exchange buffer of the output transform (overlays U and R)
   return (128 + (u + rimg > x ? u + rimg : x)) * sizeof(float);
 }
@@ -439,12 +441,12 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<z, py, px, 2, false, two>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
       if (e == hipSuccess)                                                                          \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<z, py, px, 2, true, two>), \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<z, py, px, 2, true, true>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
       if (e != hipSuccess) return e;                                                                \
       attr_set[dev & 63] = true;                                                                    \
     }                                                                                               \
-    if (f16) hipLaunchKernelGGL((conv_wino_kernel<z, py, px, 2, true, (z == 8 && py == 2 && px == 2)>), grid, dim3(256), lds, st, a);   \
+    if (f16) hipLaunchKernelGGL((conv_wino_kernel<z, py, px, 2, true, true>), grid, dim3(256), lds, st, a);   \
     else hipLaunchKernelGGL((conv_wino_kernel<z, py, px, 2, false, (z == 8 && py == 2 && px == 2)>), grid, dim3(256), lds, st, a);  \
     return hipGetLastError();                                                                       \
   }
