@@ -48,8 +48,15 @@ __device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_r
 // The one-step form evaluates GroupNorm + SiLU per patch, i.e. 1.78x per voxel (patches overlap), and the kernel is
 // vector-issue bound (10 vector instructions per MFMA, profiles/round2_pmc_summary.csv).  With TWO the fp32 U image is
 // unpadded with an XOR swizzle of the 16-byte column by (row >> 2) instead of 4 pad dwords per row.
-template <int BZ, int PY, int PX, int OCC, bool F16, bool TWO>
-__global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
+// NBW = 2 (layers with >= 64 output channels): a 512-thread workgroup computes TWO 32-channel output tiles from one
+// staged U image -- waves 0-3 the first, waves 4-7 the second -- so the staging / transform work per output halves.
+// In the one-step form the 8 waves then share the items as HALF items: lane pair (2k, 2k+1) takes patch rows
+// {0,1} / {2,3} of item k, transforms along x locally, swaps ONE transformed row with its partner (DPP quad_perm) and
+// finishes two of the four y components each -- 94 % of the lanes busy instead of 47 %.
+template <int BZ, int PY, int PX, int OCC, bool F16, bool TWO, int NBW = 1>
+__global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArgs a) {
+  constexpr int NT = 256 * NBW;
+  constexpr bool HALF = NBW == 2 && !TWO;       // half items in the one-step staging
   constexpr int NP = PY * PX, ROWS = BZ * NP;
   static_assert(ROWS <= 32 && ROWS > 16, "one (partly filled) 32-row accumulator block per frequency component");
   constexpr int HZ = BZ + 2, UR = HZ * NP;      // input planes, rows per component in LDS
@@ -57,16 +64,17 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
   static_assert(!SWZ || NP == 4, "the swizzle key of a z tap is (row >> 2) + dz");
   constexpr int CS = 16, S = F16 ? 12 : (SWZ ? CS : CS + 4);  // channel chunk, LDS row stride in dwords (conflict-free b128 for consecutive rows)
   constexpr int RYH = 2 * PY + 2, RXH = 2 * PX + 2, RV = HZ * RYH * RXH, RS_ = BZ == 8 ? 24 : 20;   // activated halo image R[RV][24] (TWO)
-  constexpr int RK = (RV * 4 + 255) / 256;       // step-A rounds per thread
+  constexpr int RK = (RV * 4 + NT - 1) / NT;     // step-A rounds per thread
   constexpr int NITEMS = HZ * NP * (CS / 4);    // staging items: (plane, patch, channel quad)
-  static_assert(NITEMS <= 256, "one staging item per thread");
+  static_assert(NITEMS <= 256, "one staging item per thread (or lane pair)");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int *outoff = reinterpret_cast<int *>(lds);   // [4 sub-blocks (a, b)][32 rows] output voxel index or -1
   float *U = lds + 128;                         // [16][UR][S]; later the exchange buffer [4 waves][2][16][64]
   float *R = U + 16 * UR * S;                   // TWO: [RV][24] normalised + activated halo of the current chunk
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wv8 & 3, nbw = wv8 >> 2;     // frequency row xi_y of this wave, its output tile within the workgroup
   const int r = lane & 31, hh = lane >> 5;
   int tile = blockIdx.x;
   if (!(gridDim.x & 7) && !(a.dbg & 4096)) tile = (tile & 7) * (int)(gridDim.x >> 3) + (tile >> 3);  // XCD-aware order (cm_conv.hip)
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
   const int ty = tile % a.nty; tile /= a.nty;
   const int tz = tile % a.ntz;
   const int b0 = tile / a.ntz;
-  const int nt = blockIdx.y;
+  const int nt = blockIdx.y * NBW + nbw;
   // patch origin of the tile (shifted back inside the grid if it would stick out) and the first patch it OWNS
   const int pyt = a.Yo >> 1, pxt = a.Xo >> 1;
   const int py0 = min(ty * PY, pyt - PY), px0 = min(tx * PX, pxt - PX);
@@ -89,20 +97,22 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
     outoff[tid] = (own && b0 < a.B && oz < a.Zo && oy < a.Yo && ox < a.Xo) ? ((b0 * a.Zo + oz) * a.Yo + oy) * a.Xo + ox : -1;
   }
   // ---- this thread's staging item: source voxel offsets of its 4x4 patch, resolved once ---------------
-  const bool stager = tid < NITEMS;
-  const int it = stager ? tid : 0;
+  const int itid = HALF ? tid >> 1 : tid, hf = HALF ? tid & 1 : 0;   // HALF: lane pair = item, hf = its patch rows {2hf, 2hf+1}
+  const bool stager = itid < NITEMS;
+  const int it = stager ? itid : 0;
   const int quad = it & 3, patch = (it >> 2) % NP, zi = it / (4 * NP);
-  int soff[16];
+  constexpr int NR = HALF ? 2 : 4;              // patch rows this thread loads
+  int soff[NR * 4];
   unsigned okmask = 0;
   {
     const int py = patch / PX, px = patch % PX;
     const int cz = z0 - 1 + zi;
     const bool zok = stager && b0 < a.B && cz >= 0 && cz < a.Zs;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NR; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int cy = y0 + 2 * py - 1 + i, cx = x0 + 2 * px - 1 + j;
+        const int cy = y0 + 2 * py - 1 + i + 2 * hf, cx = x0 + 2 * px - 1 + j;
         const bool ok = zok && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs;
         soff[i * 4 + j] = ok ? ((bs * a.Zs + cz) * a.Ys + cy) * a.Xs + cx : 0;
         okmask |= (ok ? 1u : 0u) << (i * 4 + j);
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
   if constexpr (TWO) {
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
-      const int v = (tid >> 2) + 64 * k;
+      const int v = (tid >> 2) + (NT / 4) * k;
       const int vz = v / (RYH * RXH), rem = v - vz * (RYH * RXH), vy = rem / RXH, vx = rem - vy * RXH;
       const int cz = z0 - 1 + vz, cy = y0 - 1 + vy, cx = x0 - 1 + vx;
       const bool ok = v < RV && b0 < a.B && cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs;
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
       // step A: this chunk's halo voxels (loaded during the previous matrix phase) -> activated image R
 #pragma unroll
       for (int k = 0; k < RK; ++k) {
-        const int v = (tid >> 2) + 64 * k;
+        const int v = (tid >> 2) + (NT / 4) * k;
         if (v < RV) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = activate(ald[k], (aok >> k) & 1u);
       }
       __syncthreads();                        // R complete; every wave is past the previous chunk's matrix phase
@@ -195,30 +205,46 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
     } else {
       const float *sp = src + c0 + 4 * quad;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) d[k] = *reinterpret_cast<const f32x4 *>(sp + (size_t)soff[k] * Cs);
+      for (int k = 0; k < NR * 4; ++k) d[k] = *reinterpret_cast<const f32x4 *>(sp + (size_t)soff[k] * Cs);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) d[k] = activate(d[k], (okmask >> k) & 1u);
+      for (int k = 0; k < NR * 4; ++k) d[k] = activate(d[k], (okmask >> k) & 1u);
     }
     // B^T d B: rows of B^T = (1,0,-1,0), (0,1,1,0), (0,-1,1,0), (0,1,0,-1); first along x (index j), then y (i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const f32x4 e0 = d[i * 4 + 0], e1 = d[i * 4 + 1], e2 = d[i * 4 + 2], e3 = d[i * 4 + 3];
       d[i * 4 + 0] = e0 - e2; d[i * 4 + 1] = e1 + e2; d[i * 4 + 2] = e2 - e1; d[i * 4 + 3] = e1 - e3;
     }
+    if constexpr (HALF) {
+      // lane hf = 0 holds the x-transformed patch rows 0, 1; hf = 1 rows 2, 3.  y components: V0 = t0 - t2, V1 = t1 + t2
+      // (lane 0), V2 = t2 - t1, V3 = t1 - t3 (lane 1): each lane needs its partner's INNER row (t2 resp. t1).
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j], e3 = d[3 * 4 + j];
-      d[0 * 4 + j] = e0 - e2; d[1 * 4 + j] = e1 + e2; d[2 * 4 + j] = e2 - e1; d[3 * 4 + j] = e1 - e3;
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 inner = hf ? d[j] : d[4 + j], outer = hf ? d[4 + j] : d[j];
+        f32x4 c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          c[e] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(inner[e]), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]; (__builtin_bit_cast of a vector ELEMENT reads element 0)
+        d[j] = hf ? inner - c : outer - c;          // V0 = t0 - t2   |  V2 = t2 - t1
+        d[4 + j] = hf ? c - outer : inner + c;      // V1 = t1 + t2   |  V3 = t1 - t3
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j], e3 = d[3 * 4 + j];
+        d[0 * 4 + j] = e0 - e2; d[1 * 4 + j] = e1 + e2; d[2 * 4 + j] = e2 - e1; d[3 * 4 + j] = e1 - e3;
+      }
     }
     if constexpr (!TWO) __syncthreads();    // previous chunk's fragments have been read
     if (stager) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {                                   // component xi = i * 4 + j = k
+      for (int k = 0; k < NR * 4; ++k) {                               // component xi = (2 hf + i) * 4 + j, k = i * 4 + j
+        const int xi = HALF ? 8 * hf + k : k;
         if constexpr (F16) {
           const f16x4 hv = {(_Float16)d[k][0], (_Float16)d[k][1], (_Float16)d[k][2], (_Float16)d[k][3]};
-          *reinterpret_cast<f16x4 *>(uw + (size_t)k * UR * S) = hv;
+          *reinterpret_cast<f16x4 *>(uw + (size_t)xi * UR * S) = hv;
         } else {
-          *reinterpret_cast<f32x4 *>(uw + (size_t)k * UR * S) = d[k];
+          *reinterpret_cast<f32x4 *>(uw + (size_t)xi * UR * S) = d[k];
         }
       }
     }
@@ -289,15 +315,16 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(const ConvArgs a) {
   f32x16 t0 = acc[0] + acc[1] + acc[2];
   f32x16 t1 = acc[1] - acc[2] - acc[3];
   __syncthreads();                          // U is dead: reuse as the exchange buffer
-  float *xb = U + (size_t)(wave * 2) * 16 * 64 + lane;
+  float *const XC = U + (size_t)nbw * (4 * 2 * 16 * 64);   // this output tile's exchange buffer
+  float *xb = XC + (size_t)(wave * 2) * 16 * 64 + lane;
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) { xb[reg * 64] = t0[reg]; xb[(16 + reg) * 64] = t1[reg]; }
   __syncthreads();
   const int oa = wave >> 1, ob = wave & 1;   // this wave's output sub-block
   f32x16 v;
   {
-    const float *p0 = U + (size_t)((0 * 2 + ob) * 16) * 64 + lane, *p1 = U + (size_t)((1 * 2 + ob) * 16) * 64 + lane;
-    const float *p2 = U + (size_t)((2 * 2 + ob) * 16) * 64 + lane, *p3 = U + (size_t)((3 * 2 + ob) * 16) * 64 + lane;
+    const float *p0 = XC + (size_t)((0 * 2 + ob) * 16) * 64 + lane, *p1 = XC + (size_t)((1 * 2 + ob) * 16) * 64 + lane;
+    const float *p2 = XC + (size_t)((2 * 2 + ob) * 16) * 64 + lane, *p3 = XC + (size_t)((3 * 2 + ob) * 16) * 64 + lane;
     if (oa == 0) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) v[reg] = (p0[reg * 64] + p1[reg * 64]) + p2[reg * 64];
@@ -409,12 +436,15 @@ bool conv_wino_pick(int Zo, int Yo, int Xo, int *bz, int *by, int *bx) {
 // and every tile of the f16 plan (its U image is 40 % smaller)
 bool conv_wino_two_step(int bz, int by, int bx, bool f16) { return (bz == 8 && by == 4 && bx == 4) || f16; }
 
-size_t conv_wino_lds(int bz, int by, int bx, bool f16) {
+// output tiles per workgroup: two (512 threads) for layers with a multiple of 64 output channels, except on the 8x2x2 tile
+int conv_wino_nbw(int bz, int Co) { return (bz != 8 && Co % 64 == 0) ? 2 : 1; }
+
+size_t conv_wino_lds(int bz, int by, int bx, bool f16, int nbw) {
   const size_t ur = (size_t)(bz + 2) * (by / 2) * (bx / 2);
   const bool two = conv_wino_two_step(bz, by, bx, f16);
   const size_t u = 16 * ur * (f16 ? 12 : (two ? 16 : 20));
   const size_t rimg = two ? (size_t)(bz + 2) * (by + 2) * (bx + 2) * (bz == 8 ? 24 : 20) : 0;
-  const size_t x = 4 * 2 * 16 * 64;               // exchange buffer of the output transform (overlays U and R)
+  const size_t x = (size_t)nbw * 4 * 2 * 16 * 64;  // exchange buffers of the output transform (overlay U and R)
   return (128 + (u + rimg > x ? u + rimg : x)) * sizeof(float);
 }
 
@@ -422,33 +452,38 @@ bool conv_wino_ok(const ConvArgs &a) {
   return a.ntaps == 27 && a.td == 3 && a.stride == 1 && !a.par && !a.ups && a.ks <= 1 && a.bs == 1 && (!a.s2w || (a.s2C0 % 32 == 0 && a.s2C1 % 32 == 0)) &&
          a.C0 % 16 == 0 && a.C1 % 16 == 0 && conv_wino_tile_ok(a.bz, a.by, a.bx) && a.Zo % a.bz == 0 && a.Yo % 2 == 0 && a.Xo % 2 == 0 &&
          a.by <= a.Yo && a.bx <= a.Xo && a.nty == (a.Yo + a.by - 1) / a.by && a.ntx == (a.Xo + a.bx - 1) / a.bx && a.ntz == a.Zo / a.bz &&
-         a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo && conv_wino_lds(a.bz, a.by, a.bx, false) <= 80 * 1024;
+         a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo && conv_wino_lds(a.bz, a.by, a.bx, false, conv_wino_nbw(a.bz, a.Co)) <= 80 * 1024;
 }
 
 hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
   ConvArgs a = a_in;
   a.dbg = conv_dbg_flags();
   if (!conv_wino_ok(a)) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)(a.B * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + 31) / 32));
-  const size_t lds = conv_wino_lds(a.bz, a.by, a.bx, f16);
-#define X(z, py, px)                                                                                \
-  if (a.bz == z && a.by == 2 * py && a.bx == 2 * px) {                                              \
+  const int nbw = conv_wino_nbw(a.bz, a.Co);
+  const dim3 grid((unsigned)(a.B * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + 31) / 32 / nbw));
+  const size_t lds = conv_wino_lds(a.bz, a.by, a.bx, f16, nbw);
+#define CM_WINO_GO(KERNEL, THREADS)                                                                 \
+  {                                                                                                 \
     static bool attr_set[64] = {false};                                                             \
     int dev = 0;                                                                                    \
     (void)hipGetDevice(&dev);                                                                       \
     if (!attr_set[dev & 63]) {                                                                      \
-      constexpr bool two = (z == 8 && py == 2 && px == 2);                                          \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<z, py, px, 2, false, two>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
-      if (e == hipSuccess)                                                                          \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<z, py, px, 2, true, true>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       if (e != hipSuccess) return e;                                                                \
       attr_set[dev & 63] = true;                                                                    \
     }                                                                                               \
-    if (f16) hipLaunchKernelGGL((conv_wino_kernel<z, py, px, 2, true, true>), grid, dim3(256), lds, st, a);   \
-    else hipLaunchKernelGGL((conv_wino_kernel<z, py, px, 2, false, (z == 8 && py == 2 && px == 2)>), grid, dim3(256), lds, st, a);  \
+    hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS), lds, st, a);                                    \
     return hipGetLastError();                                                                       \
+  }
+#define X(z, py, px)                                                                                \
+  if (a.bz == z && a.by == 2 * py && a.bx == 2 * px) {                                              \
+    constexpr bool two = (z == 8 && py == 2 && px == 2);                                            \
+    if constexpr (z != 8) {                                                                         \
+      if (nbw == 2 && f16) CM_WINO_GO((conv_wino_kernel<z, py, px, 2, true, true, 2>), 512)         \
+      if (nbw == 2) CM_WINO_GO((conv_wino_kernel<z, py, px, 2, false, two, 2>), 512)                \
+    }                                                                                               \
+    if (f16) CM_WINO_GO((conv_wino_kernel<z, py, px, 2, true, true, 1>), 256)                       \
+    CM_WINO_GO((conv_wino_kernel<z, py, px, 2, false, two, 1>), 256)                                \
   }
   CM_WINO_TILES(X)
 #undef X

@@ -102,7 +102,8 @@ hipError_t launch_conv_first(const ConvArgs &a, int cin, const float *wpk, hipSt
 // [64 lanes][4] transformed weights; statistics slots per tile: 4 (the (a, b) sub-blocks).
 bool conv_wino_tile_ok(int bz, int by, int bx);
 bool conv_wino_ok(const ConvArgs &a);
-size_t conv_wino_lds(int bz, int by, int bx, bool f16);
+size_t conv_wino_lds(int bz, int by, int bx, bool f16, int nbw);
+int conv_wino_nbw(int bz, int Co);
 // f16: a.wfrag holds the f16 packing (3 groups per chunk and wave, 8 halves per lane): fp32 accumulate, f16 operands
 hipError_t launch_conv_wino(const ConvArgs &a, bool f16, hipStream_t st);
 // Weight gradient in the Winograd domain (same tiles): partials part[G][ncb][nkb][3][16][32 ci][32 co], then G^T dU G
