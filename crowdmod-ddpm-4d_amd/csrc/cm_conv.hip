@@ -55,8 +55,16 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
   // FAST >= 200 (reduced-precision plan, parity form only): the staged tile is rounded to f16 (row = 32 channels
   // = 64 B + 8 B pad), the weights arrive as f16, and a wave's 8-channel slice of a tap is ONE
   // v_mfma_f32_32x32x8_f16 (fp32 accumulate) instead of four fp32 instructions
-  constexpr bool F16 = FAST >= 200;
+  constexpr bool F16 = FAST >= 200 && FAST < 300;
   static_assert(!F16 || SPAR, "f16 operands are instantiated for the specialised parity form only");
+  // FAST 327 / 427 (z-split form of a 27-tap layer whose grid has exactly TWO z planes -- the quarter resolution of
+  // every reference grid): row block mb holds the voxels of plane z = mb, so the z tap that would read the padding
+  // plane (dz = 0 for z = 0, dz = 2 for z = 1) is never issued and the padding planes are never staged: 18 instead
+  // of 27 taps of MFMAs per block and half the halo box.  Bit-identical to the full form (the skipped products are
+  // exact zeros).  427 = with the fused 1x1x1 skip convolution (as 127).
+  constexpr bool ZS = SPEC && FAST >= 300;
+  static_assert(!ZS || (MB == 2 && BZ == 2 && BY * BX <= 32 && STR == 1 && (FAST % 100) == 27), "z-split: one plane per row block");
+  constexpr bool SKIPC = FAST == 127 || FAST == 427;
   constexpr int STD = SPAR ? 2 : 3;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TM = 32 * MB;
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
   const int os = a_par ? 2 : 1;
   const int pad = (a_td == 3) ? 1 : 0;
   const int td = a_td;
-  const int HZ = (a_bz - 1) * a_stride + td;
+  const int HZ = ZS ? 2 : (a_bz - 1) * a_stride + td;
   const int HY = (a_by - 1) * a_stride + td;
   const int HX = (a_bx - 1) * a_stride + td;
   const int HV1 = HZ * HY * HX;
@@ -118,7 +126,10 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
   const int nbox = a_bs * a_bz * a_by * a_bx;
   // packed row / halo coordinates: host tables in general, arithmetic (constant divisors) when specialised
   auto mtab_at = [&](int m) -> int {
-    if constexpr (SPEC) {
+    if constexpr (ZS) {
+      const int rr = m & 31, y = rr / BX, x = rr - y * BX;
+      return rr < BY * BX ? ((m >> 5) << 18) | (y << 9) | x : -1;
+    } else if constexpr (SPEC) {
       if (m >= BZ * BY * BX) return -1;
       const int z = m / (BY * BX), rem = m - z * (BY * BX), y = rem / BX, x = rem - y * BX;
       return (z << 18) | (y << 9) | x;
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
     if (tid < TM) { outoff[tid] = off; outb[tid] = bb; }
   }
   const int Zc = a.Zs << a_ups, Yc = a.Ys << a_ups, Xc = a.Xs << a_ups;
-  const int cz0 = z0 * a_stride + (a_par ? pz - 1 : -pad), cy0 = y0 * a_stride + (a_par ? py - 1 : -pad),
+  const int cz0 = ZS ? 0 : z0 * a_stride + (a_par ? pz - 1 : -pad), cy0 = y0 * a_stride + (a_par ? py - 1 : -pad),
             cx0 = x0 * a_stride + (a_par ? px - 1 : -pad);
 
   // ---- per-lane LDS row base of each of this wave's MB row blocks -----------
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
   for (int mb = 0; mb < MB; ++mb) {
     const int pk = pk_ab[mb] >= 0 ? pk_ab[mb] : 0;
     const int x = pk & 511, y = (pk >> 9) & 511, z = (pk >> 18) & 255, s = pk >> 26;
-    const int hv = ((s * HZ + z * a_stride) * HY + y * a_stride) * HX + x * a_stride;
+    const int hv = ((s * HZ + (ZS ? 0 : z) * a_stride) * HY + y * a_stride) * HX + x * a_stride;   // ZS: plane 0, the tap adds mb + dz - 1
     abase[mb] = hv * S + (F16 ? 2 : 4) * h;
   }
 
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
   // loads back to back (one memory latency per chunk instead of one per dependent step --
   // a global load costs 1.5-2 us under load on this part, profiles/round1_notes.md).
   // halo float4 per thread: 12 (HV <= 384) in general; a specialisation sizes it to its own box
-  constexpr int cHZs = (BZ - 1) * STR + STD, cHYs = (BY - 1) * STR + STD, cHXs = (BX - 1) * STR + STD;
+  constexpr int cHZs = ZS ? 2 : (BZ - 1) * STR + STD, cHYs = (BY - 1) * STR + STD, cHXs = (BX - 1) * STR + STD;
   constexpr int cRJ = (cHZs * cHYs + 31) / 32;
   constexpr int NVM = !SPEC ? 12
                       : (cRJ <= 2 && cRJ * cHXs <= 16 && cRJ * cHXs > 12) ? 16                 // row mode, 13-16 slots
@@ -389,7 +400,43 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
     if (ch == ch0) { CM_RT(2) }
     // ---- this wave's share of the (tap, 8-channel) steps ---------------------
     if (a.dbg & 2) continue;
-    if constexpr (fast) {
+    if constexpr (ZS) {
+      // all 27 taps unrolled: LDS offsets are immediates, and a row block skips the z tap that reads its padding plane
+      auto zs_on = [](int t, int mb) { const int dz = t / 9; return mb == 0 ? dz >= 1 : dz <= 1; };
+      auto zs_off = [&](int t, int mb) { const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3; return (((mb + dz - 1) * cHYs + dy) * cHXs + dx) * 36; };
+      const float *Aw = A + wave * 8;
+      f32x4 afn[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) afn[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+        if (zs_on(0, mb)) afn[mb] = *reinterpret_cast<const f32x4 *>(&Aw[abase[mb] + zs_off(0, mb)]);
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        const int d = t % PD;
+        f32x4 af[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) af[mb] = afn[mb];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          if (t + 1 < 27 && zs_on(t + 1, mb)) afn[mb] = *reinterpret_cast<const f32x4 *>(&Aw[abase[mb] + zs_off(t + 1, mb)]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+            if (zs_on(t, mb)) {
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mb][jj], bq[d][nb][jj], acc[mb][nb], 0, 0, 0);
+            }
+        if (wleft > 0) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) bq[d][nb] = wrun[nb * 64];
+          wrun += 4 * NB * 64;
+          --wleft;
+        }
+      }
+    } else if constexpr (fast) {
       // 27 taps x 4 k8-steps = 108 steps per chunk, 27 per wave: wave w owns channels
       // [8w, 8w+8) of the chunk for every tap.  Weight fragments run PD steps ahead of
       // the MFMAs in a register ring (static indices: 27 = 9 x PD) and the stream
@@ -495,7 +542,7 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
     }
   }
 
-  if constexpr (FAST == 127) {
+  if constexpr (SKIPC) {
     if (a.s2w && kz == 0) {
       // ---- fused 1x1x1 skip convolution: K chunks over the raw block input, centre tap ----
       const int n2a = a.s2C0 >> 5, n2 = (a.s2C0 + a.s2C1) >> 5;
@@ -787,6 +834,17 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
     if (a.s2w) CM_LAUNCH_T((conv_mfma_kernel<m, n, 127, z, y, x, 1, 3>), m, n, 127) \
     CM_LAUNCH_T((conv_mfma_kernel<m, n, 27, z, y, x, 1, 3>), m, n, 27)             \
   }
+  // z-split form: grids with exactly two z planes (quarter resolution), one plane per row block
+  const bool zsok = specok && a.Zo == 2 && a.Zs == 2 && a.ntz == 1 && MB == 2 && NB == 2 && a.bz == 2 && !(dbg & 16384);
+#define CM_SPEC_ZS(y, x)                                                           \
+  if (zsok && a.by == y && a.bx == x) {                                            \
+    if (a.s2w) CM_LAUNCH_T((conv_mfma_kernel<2, 2, 427, 2, y, x>), 2, 2, 427)      \
+    CM_LAUNCH_T((conv_mfma_kernel<2, 2, 327, 2, y, x>), 2, 2, 327)                 \
+  }
+  CM_SPEC_ZS(3, 9)   // ATC 3 x 9 x 2
+  CM_SPEC_ZS(6, 5)   // 2x grid 6 x 18 x 2
+  CM_SPEC_ZS(7, 4)   // HERMES-CR-120 7 x 6 x 2
+#undef CM_SPEC_ZS
   CM_SPEC3(3, 1, 8, 6, 2)  // full resolution, three workgroups per CU (128 VGPRs): -7 % vs MB4 8x4x4 at 2 per CU
   CM_SPEC3(3, 1, 8, 4, 3)  //   (8x3x4, 4x4x6, 4x6x4, 8x2x6 measured slower: 118 / 136 / 111 / 134 us vs 108 on the 32->32 layer)
 #undef CM_SPEC3

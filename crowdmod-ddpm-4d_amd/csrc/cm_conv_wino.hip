@@ -60,8 +60,7 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
   constexpr int NP = PY * PX, ROWS = BZ * NP;
   static_assert(ROWS <= 32 && ROWS > 16, "one (partly filled) 32-row accumulator block per frequency component");
   constexpr int HZ = BZ + 2, UR = HZ * NP;      // input planes, rows per component in LDS
-  constexpr bool SWZ = TWO && !F16;              // unpadded fp32 rows, 16-byte column XOR-swizzled by (row >> 2) & 3
-  static_assert(!SWZ || NP == 4, "the swizzle key of a z tap is (row >> 2) + dz");
+  constexpr bool SWZ = TWO && !F16 && PY * PX == 4;   // unpadded fp32 rows, 16-byte column XOR-swizzled by (row >> 2) & 3
   constexpr int CS = 16, S = F16 ? 12 : (SWZ ? CS : CS + 4);  // channel chunk, LDS row stride in dwords (conflict-free b128 for consecutive rows)
   constexpr int RYH = 2 * PY + 2, RXH = 2 * PX + 2, RV = HZ * RYH * RXH, RS_ = BZ == 8 ? 24 : 20;   // activated halo image R[RV][24] (TWO)
   constexpr int RK = (RV * 4 + NT - 1) / NT;     // step-A rounds per thread
@@ -167,11 +166,17 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
     for (int k = 0; k < RK; ++k) ald[k] = *reinterpret_cast<const f32x4 *>(sp0 + (size_t)asoff[k] * a.C0);
   }
 
+  f32x4 dn[TWO ? 1 : NR * 4];                    // one-step form: raw patch loads of the NEXT chunk, in flight during the matrix phase
+  constexpr bool PRE = HALF;                     // (the full-item one-step form would spill with 16 more loads held)
+  if constexpr (PRE) {
+    const float *sp0 = a.src0 + 4 * quad;
+#pragma unroll
+    for (int k = 0; k < NR * 4; ++k) dn[k] = *reinterpret_cast<const f32x4 *>(sp0 + (size_t)soff[k] * a.C0);
+  }
+
   for (int ch = 0; ch < nchunks; ++ch) {
-    const float *src;
-    int Cs, c0, cg0;
-    if (ch < n0) { src = a.src0; Cs = a.C0; c0 = ch * CS; cg0 = c0; }
-    else { src = a.src1; Cs = a.C1; c0 = (ch - n0) * CS; cg0 = a.C0 + c0; }
+    int cg0;
+    if (ch < n0) cg0 = ch * CS; else cg0 = a.C0 + (ch - n0) * CS;
     // ---- stage + input transform ---------------------------------------------------------------------
     f32x4 d[16];
     f32x4 sc1 = {1.f, 1.f, 1.f, 1.f}, sh1 = {0.f, 0.f, 0.f, 0.f}, pm1 = {1.f, 1.f, 1.f, 1.f};
@@ -203,11 +208,14 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[i * 4 + j] = *reinterpret_cast<const f32x4 *>(R + rbase + (i * RXH + j) * RS_);
     } else {
-      const float *sp = src + c0 + 4 * quad;
+      if constexpr (!PRE) {
+        const float *sp = (ch < n0 ? a.src0 + ch * CS : a.src1 + (ch - n0) * CS) + 4 * quad;
+        const int Cs = ch < n0 ? a.C0 : a.C1;
 #pragma unroll
-      for (int k = 0; k < NR * 4; ++k) d[k] = *reinterpret_cast<const f32x4 *>(sp + (size_t)soff[k] * Cs);
+        for (int k = 0; k < NR * 4; ++k) dn[k] = *reinterpret_cast<const f32x4 *>(sp + (size_t)soff[k] * Cs);
+      }
 #pragma unroll
-      for (int k = 0; k < NR * 4; ++k) d[k] = activate(d[k], (okmask >> k) & 1u);
+      for (int k = 0; k < NR * 4; ++k) d[k] = activate(dn[k], (okmask >> k) & 1u);
     }
     // B^T d B: rows of B^T = (1,0,-1,0), (0,1,1,0), (0,-1,1,0), (0,1,0,-1); first along x (index j), then y (i)
 #pragma unroll
@@ -249,13 +257,16 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
       }
     }
     __syncthreads();
-    if constexpr (TWO) {                      // next chunk's halo loads: in flight under this chunk's matrix phase
-      if (ch + 1 < nchunks) {
-        const int cn = ch + 1;
-        const float *spn = (cn < n0 ? a.src0 + cn * CS : a.src1 + (cn - n0) * CS) + 4 * aq;
-        const int Cn = cn < n0 ? a.C0 : a.C1;
+    if (ch + 1 < nchunks) {                   // next chunk's loads: in flight under this chunk's matrix phase
+      const int cn = ch + 1;
+      const float *spn = (cn < n0 ? a.src0 + cn * CS : a.src1 + (cn - n0) * CS) + 4 * (TWO ? aq : quad);
+      const int Cn = cn < n0 ? a.C0 : a.C1;
+      if constexpr (TWO) {
 #pragma unroll
         for (int k = 0; k < RK; ++k) ald[k] = *reinterpret_cast<const f32x4 *>(spn + (size_t)asoff[k] * Cn);
+      } else if constexpr (PRE) {
+#pragma unroll
+        for (int k = 0; k < NR * 4; ++k) dn[k] = *reinterpret_cast<const f32x4 *>(spn + (size_t)soff[k] * Cn);
       }
     }
     // ---- matrix phase: NG groups (z tap [, 8-channel half]) x 4 components ---------------------------------
@@ -434,15 +445,15 @@ bool conv_wino_pick(int Zo, int Yo, int Xo, int *bz, int *by, int *bx) {
 
 // two-step staging where the activated halo image fits next to U at two workgroups per CU: the full-resolution tile,
 // and every tile of the f16 plan (its U image is 40 % smaller)
-bool conv_wino_two_step(int bz, int by, int bx, bool f16) { return (bz == 8 && by == 4 && bx == 4) || f16; }
+bool conv_wino_two_step(int bz, int by, int bx, bool f16, int nbw) { return (bz == 8 && by == 4 && bx == 4) || f16 || nbw == 2; }
 
 // output tiles per workgroup: two (512 threads) for layers with a multiple of 64 output channels, except on the 8x2x2 tile
 int conv_wino_nbw(int bz, int Co) { return (bz != 8 && Co % 64 == 0) ? 2 : 1; }
 
 size_t conv_wino_lds(int bz, int by, int bx, bool f16, int nbw) {
   const size_t ur = (size_t)(bz + 2) * (by / 2) * (bx / 2);
-  const bool two = conv_wino_two_step(bz, by, bx, f16);
-  const size_t u = 16 * ur * (f16 ? 12 : (two ? 16 : 20));
+  const bool two = conv_wino_two_step(bz, by, bx, f16, nbw);
+  const size_t u = 16 * ur * (f16 ? 12 : ((two && by * bx == 16) ? 16 : 20));   // (swizzled unpadded rows on the 2 x 2 patch tile)
   const size_t rimg = two ? (size_t)(bz + 2) * (by + 2) * (bx + 2) * (bz == 8 ? 24 : 20) : 0;
   const size_t x = (size_t)nbw * 4 * 2 * 16 * 64;  // exchange buffers of the output transform (overlay U and R)
   return (128 + (u + rimg > x ? u + rimg : x)) * sizeof(float);
@@ -452,7 +463,7 @@ bool conv_wino_ok(const ConvArgs &a) {
   return a.ntaps == 27 && a.td == 3 && a.stride == 1 && !a.par && !a.ups && a.ks <= 1 && a.bs == 1 && (!a.s2w || (a.s2C0 % 32 == 0 && a.s2C1 % 32 == 0)) &&
          a.C0 % 16 == 0 && a.C1 % 16 == 0 && conv_wino_tile_ok(a.bz, a.by, a.bx) && a.Zo % a.bz == 0 && a.Yo % 2 == 0 && a.Xo % 2 == 0 &&
          a.by <= a.Yo && a.bx <= a.Xo && a.nty == (a.Yo + a.by - 1) / a.by && a.ntx == (a.Xo + a.bx - 1) / a.bx && a.ntz == a.Zo / a.bz &&
-         a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo && conv_wino_lds(a.bz, a.by, a.bx, false, conv_wino_nbw(a.bz, a.Co)) <= 80 * 1024;
+         a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo && conv_wino_lds(a.bz, a.by, a.bx, false, conv_wino_nbw(a.bz, a.Co)) <= (conv_wino_nbw(a.bz, a.Co) == 2 ? 160 : 80) * 1024;
 }
 
 hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
@@ -480,7 +491,7 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
     constexpr bool two = (z == 8 && py == 2 && px == 2);                                            \
     if constexpr (z != 8) {                                                                         \
       if (nbw == 2 && f16) CM_WINO_GO((conv_wino_kernel<z, py, px, 2, true, true, 2>), 512)         \
-      if (nbw == 2) CM_WINO_GO((conv_wino_kernel<z, py, px, 2, false, two, 2>), 512)                \
+      if (nbw == 2) CM_WINO_GO((conv_wino_kernel<z, py, px, 2, false, true, 2>), 512)               \
     }                                                                                               \
     if (f16) CM_WINO_GO((conv_wino_kernel<z, py, px, 2, true, true, 1>), 256)                       \
     CM_WINO_GO((conv_wino_kernel<z, py, px, 2, false, two, 1>), 256)                                \

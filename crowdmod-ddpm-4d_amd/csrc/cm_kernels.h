@@ -183,6 +183,8 @@ struct StepArgs {
   const StepRow *tab; const int *kctr;
   long long row_stride;  // Bfull * per
   long long boff;        // b0 * per
+  // plain loop: this step also writes the NEXT step's time index into the UNet's t buffer (saves a launch per step)
+  long long *t_next; long long t_next_v;
 };
 hipError_t launch_sampler_step(const StepArgs &a, hipStream_t st);
 hipError_t launch_q_sample(const float *x0, const long long *t, const float *eps, const float *sab, const float *s1m,

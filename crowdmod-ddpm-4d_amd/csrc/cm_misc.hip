@@ -618,6 +618,7 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(StepArgs a) {
   const long long per = (long long)a.C * a.H * a.W * a.F;
   const long long total = per * a.B;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (a.t_next && i < a.B) a.t_next[i] = a.t_next_v;   // (the UNet of this step has consumed the buffer)
   if (i >= total) return;
   const long long b = i / per, e = i - b * per;
   const int f = (int)(e % a.F);

@@ -1799,10 +1799,11 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
     for (int ln = 0; ln < lanes; ++ln) {
       const int b0 = off[ln], Bn = Bl[ln];
       hipStream_t ls = sts[ln];
-      CM_HIP(cm::launch_fill_t(m->tbuf + b0, Bn, t, ls));
+      if (k == 0) CM_HIP(cm::launch_fill_t(m->tbuf + b0, Bn, t, ls));
       if (run_ops(m, Bn, ls, b0, ln)) return 1;
       cm::StepArgs al = a;
       al.B = Bn;
+      if (k + 1 < order.size()) { al.t_next = m->tbuf + b0; al.t_next_v = order[k + 1]; }
       al.x = m->xstate + (size_t)b0 * per;
       al.eps_cl = m->eps_cl + (size_t)b0 * m->L() * c.rows * c.cols * 8;
       al.x8 = m->x8 + (size_t)b0 * m->L() * c.rows * c.cols * 8;
