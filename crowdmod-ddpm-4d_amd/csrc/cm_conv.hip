@@ -123,7 +123,6 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
   const int HV = a_bs * HV1;
   const int HVp = (HV + 3) & ~3;
   const int S = F16 ? 18 : (SPEC ? 32 : a.CK) + 4;   // LDS row stride in dwords
-  const int nbox = a_bs * a_bz * a_by * a_bx;
   // packed row / halo coordinates: host tables in general, arithmetic (constant divisors) when specialised
   auto mtab_at = [&](int m) -> int {
     if constexpr (ZS) {

@@ -130,8 +130,15 @@ struct CombineArgs {
   const float *resid; int res_cs;
   float *out; int C, V, B;
   float *stat_part; float *stat_cnt; int nslots;
+  // optional fused GroupNorm finalisation of the CONSUMER (launch_combine_gn: one workgroup per sample, V <= 64):
+  // statistics of this tensor (channels [0, C)) and of a second, finished tensor (channels [C, C + fin_C1), its
+  // slot partials fin_p1 / fin_n1) -> scale / shift per (sample, channel) as launch_gn_finalize writes them
+  const float *fin_gamma, *fin_beta; float *fin_gn, *fin_mr;
+  const float *fin_p1, *fin_n1; int fin_ns1, fin_C1, fin_groups; float fin_eps;
 };
 hipError_t launch_ksplit_combine(const CombineArgs &a, hipStream_t st);
+bool combine_gn_ok(const CombineArgs &a);
+hipError_t launch_combine_gn(const CombineArgs &a, hipStream_t st);
 // reference layout [B,C,H,W,P] + [B,C,H,W,F]  ->  channels-last [B][P+F][H][W][8]
 hipError_t launch_assemble_input(const float *past, const float *future, float *x8, int B, int C, int H, int W,
                                  int P, int F, int which /*1 past,2 future,3 both*/, hipStream_t st);

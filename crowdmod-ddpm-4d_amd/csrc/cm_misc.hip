@@ -211,16 +211,24 @@ __global__ __launch_bounds__(1024) void ksplit_combine_kernel(const CombineArgs 
     vals[i] = 0.f;
   }
   // partial sums in the fixed order s = 0..S-1; the loads of one s for all rows go out together
-  for (int s = 0; s < a.S; ++s) {
-    float p[RPT];
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) p[i] = part[(size_t)s * a.stride + idx[i]];
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) vals[i] += p[i];
-  }
   float rs[RPT];
 #pragma unroll
   for (int i = 0; i < RPT; ++i) rs[i] = (resid && ok[i]) ? resid[(idx[i] / a.C) * a.res_cs + c] : 0.f;
+  for (int s0 = 0; s0 < a.S; s0 += 4) {      // four partials per round, all their loads in flight together
+    float p[4][RPT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t so = (size_t)min(s0 + u, a.S - 1) * a.stride;
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) p[u][i] = part[so + idx[i]];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (s0 + u < a.S) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) vals[i] += p[u][i];
+      }
+  }
   float s1 = 0.f;
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
@@ -256,6 +264,187 @@ __global__ __launch_bounds__(1024) void ksplit_combine_kernel(const CombineArgs 
 hipError_t launch_ksplit_combine(const CombineArgs &a, hipStream_t st) {
   if (a.C > 256 || a.C < 1) return hipErrorInvalidValue;
   hipLaunchKernelGGL(ksplit_combine_kernel, dim3(a.nslots, a.B), dim3(1024), 0, st, a);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
+// K-split second pass + the GroupNorm finalisation of the layer that consumes the result, in one launch: a tiny
+// launch costs ~5 us on this part whatever it does, and the quarter-resolution layers paid it twice per conv
+// (ksplit_combine + gn_finalize).  grid B, 1024 threads: the workgroup runs the ksplit_combine body for each of the
+// sample's (at most two) 32-row slots -- same thread mapping and summation order, so the slot statistics it
+// writes are the ones the two-launch path writes -- then merges the slots per channel, adds the channels of the
+// concatenated second tensor from its finished partials, and folds group mean / rstd with the affine exactly as
+// gn_finalize_kernel does (layers.py:30,41; unet.py:119).
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void combine_gn_kernel(const CombineArgs a) {
+  __shared__ float red[2][1024];
+  __shared__ float cmean[1024], cm2[1024], gmean[32], grstd[32];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nl = 1024 / a.C;
+  const int c = tid % a.C, rl = tid / a.C;
+  const bool act = rl < nl;
+  const float *__restrict__ part = a.part;
+  const float *__restrict__ resid = a.resid;
+  const int Ct = a.C + a.fin_C1;
+  // the second tensor's partials (independent of everything below): first four slots in flight from the start
+  constexpr int PS = 4;
+  float n1v[PS];
+  float2 q1v[PS];
+  const int cc1 = tid - a.C;
+  const bool has1 = tid >= a.C && tid < Ct;
+#pragma unroll
+  for (int u = 0; u < PS; ++u) {
+    const bool o = has1 && u < a.fin_ns1;
+    n1v[u] = o ? a.fin_n1[(size_t)b * a.fin_ns1 + u] : 0.f;
+    q1v[u] = o ? *reinterpret_cast<const float2 *>(a.fin_p1 + (((size_t)b * a.fin_ns1 + u) * a.fin_C1 + cc1) * 2) : float2{0.f, 0.f};
+  }
+  float add = 0.f;
+  if (act) {
+    add = a.bias[c];
+    if (a.temb) add += a.temb[(size_t)a.tidx[b] * a.temb_stride + c];
+  }
+  constexpr int RPT = 8, NS = 2;
+  float vals[NS][RPT];
+  int idx[NS][RPT];                 // (host checks B * V * C < 2^31)
+  bool ok[NS][RPT];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int row = s * 32 + rl + i * nl;
+      ok[s][i] = act && s < a.nslots && i * nl < 32 && row < min(a.V, s * 32 + 32);
+      idx[s][i] = ok[s][i] ? (b * a.V + row) * a.C + c : 0;
+      vals[s][i] = 0.f;
+    }
+  // residual first, then the partials two at a time: every load of a round is in flight before the first add
+  // (one memory round trip per round instead of one per partial); the sum order stays k = 0..S-1
+  float rs[NS][RPT];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) rs[s][i] = (resid && ok[s][i]) ? resid[(size_t)(b * a.V + s * 32 + rl + i * nl) * a.res_cs + c] : 0.f;
+  for (int k0 = 0; k0 < a.S; k0 += 2) {
+    float p[2][NS][RPT];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t ko = (size_t)min(k0 + u, a.S - 1) * a.stride;
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) p[u][s][i] = part[ko + idx[s][i]];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (k0 + u < a.S) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int i = 0; i < RPT; ++i) vals[s][i] += p[u][s][i];
+      }
+  }
+  // both slots go through the reductions together (two LDS rows): four barriers in all
+  float mean_s[NS], m2_s[NS], n_s[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      vals[s][i] = ok[s][i] ? vals[s][i] + add + rs[s][i] : 0.f;
+      if (ok[s][i]) { a.out[idx[s][i]] = vals[s][i]; s1 += vals[s][i]; }
+    }
+    red[s][tid] = s1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    float tot = 0.f;
+    if (act)
+      for (int l = 0; l < nl; ++l) tot += red[s][l * a.C + c];
+    n_s[s] = (float)max(0, min(a.V, s * 32 + 32) - s * 32);
+    mean_s[s] = n_s[s] > 0.f ? tot / n_s[s] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i)
+      if (ok[s][i]) { const float d = vals[s][i] - mean_s[s]; q += d * d; }
+    red[s][tid] = q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    float m2 = 0.f;
+    if (act && rl == 0) {
+      for (int l = 0; l < nl; ++l) m2 += red[s][l * a.C + c];
+      if (s < a.nslots && a.stat_part) {
+        float *sp = a.stat_part + (((size_t)b * a.nslots + s) * a.C + c) * 2;
+        sp[0] = mean_s[s];
+        sp[1] = m2;
+        if (c == 0) a.stat_cnt[(size_t)b * a.nslots + s] = n_s[s];
+      }
+    }
+    m2_s[s] = m2;
+    if (s >= a.nslots) n_s[s] = 0.f;
+  }
+  // ---- GroupNorm finalisation of the consumer: per-channel triples, then the groups ----
+  if (tid < Ct) {
+    float N = 0.f, M = 0.f, S2 = 0.f;
+    if (tid < a.C) {                       // (tid < C  =>  rl == 0, c == tid: this thread merged the row lanes above)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) chan_combine(N, M, S2, n_s[s], mean_s[s], m2_s[s]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < PS; ++u) chan_combine(N, M, S2, n1v[u], q1v[u].x, q1v[u].y);
+      for (int u = PS; u < a.fin_ns1; ++u)
+        chan_combine(N, M, S2, a.fin_n1[(size_t)b * a.fin_ns1 + u], a.fin_p1[(((size_t)b * a.fin_ns1 + u) * a.fin_C1 + cc1) * 2],
+                     a.fin_p1[(((size_t)b * a.fin_ns1 + u) * a.fin_C1 + cc1) * 2 + 1]);
+    }
+    cmean[tid] = M;
+    cm2[tid] = S2;
+  }
+  __syncthreads();
+  // groups: 8 lanes per group merge a strided share of its channels, lane 0 merges the 8 shares (both in a fixed
+  // order); the whole step lives in the first waves, shares exchanged by shuffles
+  const int cg = Ct / a.fin_groups;
+  if (tid < a.fin_groups * 8) {
+    const int g = tid >> 3, j = tid & 7;
+    float N = 0.f, M = 0.f, S2 = 0.f;
+    for (int i = j; i < cg; i += 8) chan_combine(N, M, S2, (float)a.V, cmean[g * cg + i], cm2[g * cg + i]);
+    float GN = 0.f, GM = 0.f, GS = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float nk = __shfl(N, (tid & ~7) + k), mk = __shfl(M, (tid & ~7) + k), sk = __shfl(S2, (tid & ~7) + k);
+      chan_combine(GN, GM, GS, nk, mk, sk);
+    }
+    if (j == 0) {
+      gmean[g] = GM;
+      grstd[g] = rsqrtf(GS / GN + a.fin_eps);
+    }
+  }
+  __syncthreads();
+  if (tid < Ct) {
+    const int g = tid / cg;
+    const float sc = grstd[g] * a.fin_gamma[tid];
+    a.fin_gn[((size_t)b * 2 + 0) * Ct + tid] = sc;
+    a.fin_gn[((size_t)b * 2 + 1) * Ct + tid] = a.fin_beta[tid] - gmean[g] * sc;
+    if (a.fin_mr) {
+      a.fin_mr[((size_t)b * 2 + 0) * Ct + tid] = gmean[g];
+      a.fin_mr[((size_t)b * 2 + 1) * Ct + tid] = grstd[g];
+    }
+  }
+}
+
+bool combine_gn_ok(const CombineArgs &a) {
+  const int Ct = a.C + a.fin_C1;
+  return a.C >= 1 && a.C <= 256 && a.V <= 64 && (long long)a.B * a.V * a.C < (1ll << 31) && a.nslots <= 2 && Ct <= 1024 && a.fin_groups >= 1 && a.fin_groups <= 32 && a.fin_groups * 8 <= 1024 &&
+         Ct % a.fin_groups == 0 && a.stat_part;
+}
+
+hipError_t launch_combine_gn(const CombineArgs &a, hipStream_t st) {
+  if (!combine_gn_ok(a) || !a.fin_gn) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(combine_gn_kernel, dim3(a.B), dim3(1024), 0, st, a);
   return hipGetLastError();
 }
 

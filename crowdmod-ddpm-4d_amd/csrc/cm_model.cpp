@@ -183,6 +183,11 @@ struct cm_model {
   struct cm_train_state *train = nullptr;
   float *dropmask = nullptr;    // [B][nproj] Dropout3d keep-mask/(1-p) of the current training forward
   bool train_fwd = false;
+  // run_ops -> run_conv / fused attention: the GroupNorm finalisation op that follows a K-split layer and can ride in
+  // its second pass (cm::launch_combine_gn); `fin_done` reports that it did
+  const struct Op *fin_next = nullptr;
+  int fin_b0 = 0;
+  bool fin_done = false;
   // training step: time-embedding projections of the batch computed from the live weights
   float *train_temb = nullptr;  // [B][nproj], row b
   long long *train_iota = nullptr;
@@ -1048,6 +1053,8 @@ int build_time_table(cm_model *m) {
 // forward
 // ------------------------------------------------------------------------------
 // One convolution op of the plan for the `B` samples starting at `b0` (see run_ops).
+int run_combine(cm_model *m, cm::CombineArgs &cb, hipStream_t st);
+
 int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   if (op.skip_if_fused && !m->train_fwd) return 0;  // absorbed by the block's conv_2 (inference plan)
   if (op.tuned_B < 0 && op.wino) {
@@ -1134,7 +1141,7 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     cb.stat_part = op.stat_act->part + (size_t)b0 * cb.nslots * cb.C * 2;
     cb.stat_cnt = op.stat_act->cnt + (size_t)b0 * cb.nslots;
     op.stat_act->nslots = cb.nslots;
-    CM_HIP(cm::launch_ksplit_combine(cb, st));
+    if (run_combine(m, cb, st)) return 1;
   } else if (op.wino) {
     // reduced-precision plan: f16 operands in the inference forward; the training forward stays fp32
     const bool f16 = op.d_wwino16 && !m->train_fwd;
@@ -1153,6 +1160,32 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   return 0;
 }
 
+// Second pass of a K-split layer (or the head sum of the fused attention block): with the consumer's GroupNorm
+// finalisation fused when run_ops found one waiting (m->fin_next) and the shapes allow it.
+int run_combine(cm_model *m, cm::CombineArgs &cb, hipStream_t st) {
+  static const bool no_fuse = getenv("CM_NO_FUSE_GNFIN") != nullptr;
+  const Op *f = m->fin_next;
+  m->fin_done = false;
+  if (f && !no_fuse && (!f->g1 || f->g1->V() == cb.V)) {
+    const Act *g1 = f->g1;
+    const int b0 = m->fin_b0, Ct = cb.C + (g1 ? g1->C : 0);
+    cb.fin_gamma = f->gamma; cb.fin_beta = f->beta;
+    cb.fin_gn = f->gn_out + (size_t)b0 * 2 * Ct;
+    cb.fin_mr = f->gn_mr ? f->gn_mr + (size_t)b0 * 2 * Ct : nullptr;
+    cb.fin_p1 = g1 ? g1->part + (size_t)b0 * g1->nslots * g1->C * 2 : nullptr;
+    cb.fin_n1 = g1 ? g1->cnt + (size_t)b0 * g1->nslots : nullptr;
+    cb.fin_ns1 = g1 ? g1->nslots : 0; cb.fin_C1 = g1 ? g1->C : 0;
+    cb.fin_groups = GN_GROUPS; cb.fin_eps = GN_EPS;
+    if (cm::combine_gn_ok(cb)) {
+      CM_HIP(cm::launch_combine_gn(cb, st));
+      m->fin_done = true;
+      return 0;
+    }
+  }
+  CM_HIP(cm::launch_ksplit_combine(cb, st));
+  return 0;
+}
+
 // Launch the op list for the `B` samples starting at sample `b0` on stream `st`.
 // Every sample-indexed pointer is offset by b0, so two disjoint sub-batches can run
 // concurrently on two streams (`slab` selects the stream's K-split scratch region).
@@ -1166,6 +1199,15 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
       CM_HIP(hipEventCreate(&e0));
       CM_HIP(hipEventCreate(&e1));
       CM_HIP(hipEventRecord(e0, st));
+    }
+    // a K-split layer's second pass can carry the GroupNorm finalisation of the op that consumes its output
+    m->fin_next = nullptr; m->fin_done = false;
+    size_t fin_at = 0;
+    if ((op.kind == OP_CONV && op.ks > 1) || op.kind == OP_ATTNBLK) {
+      const Act *produced = op.kind == OP_CONV ? op.out_act : op.ab_out;
+      size_t j = oi + 1;
+      while (j < m->ops.size() && (m->ops[j].kind == OP_ATTNBLK ? m->train_fwd : (m->ops[j].in_attn_block && !m->train_fwd))) ++j;
+      if (j < m->ops.size() && m->ops[j].kind == OP_GNFIN && m->ops[j].g0 == produced) { m->fin_next = &m->ops[j]; m->fin_b0 = b0; fin_at = j; }
     }
     switch (op.kind) {
       case OP_CONV:
@@ -1211,7 +1253,7 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
         cb.stat_part = op.ab_out->part + (size_t)b0 * cb.nslots * cb.C * 2;
         cb.stat_cnt = op.ab_out->cnt + (size_t)b0 * cb.nslots;
         op.ab_out->nslots = cb.nslots;
-        CM_HIP(cm::launch_ksplit_combine(cb, st));
+        if (run_combine(m, cb, st)) return 1;
         break;
       }
     }
@@ -1219,6 +1261,8 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
       CM_HIP(hipEventRecord(e1, st));
       m->prof_events.push_back({(int)oi, {e0, e1}});
     }
+    if (m->fin_done) oi = fin_at;   // (the ops in between are the ones this mode skips anyway)
+    m->fin_next = nullptr; m->fin_done = false;
   }
   return 0;
 }
