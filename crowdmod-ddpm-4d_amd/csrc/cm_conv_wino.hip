@@ -33,6 +33,88 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
+// Epilogue of one 32-voxel x 32-channel output sub-block (same arithmetic as the direct kernel's): bias, time-embedding
+// row, residual, channels-last store, GroupNorm statistics of the block in the slot format of gn_finalize.
+__device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const f32x16 &v, const int *outoff, int nt, int wave, int lane,
+                                              int b0, int bs, int slot) {
+  const int r = lane & 31, hh = lane >> 5;
+  const int n = nt * 32 + r;
+  const bool nok = n < a.Co;
+  const int nc = nok ? n : 0;
+  const float bias = a.bias[nc];
+  int offs[16];
+  float rs[16];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) offs[reg] = outoff[wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) rs[reg] = v[reg] + bias;
+  if (a.temb) {
+    const float tv = a.temb[(size_t)a.tidx[bs] * a.temb_stride + nc];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) rs[reg] += tv;
+  }
+  if (a.resid) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int oc = offs[reg] >= 0 ? offs[reg] : 0;
+      rs[reg] += a.resid[(size_t)oc * a.res_cs + nc];
+    }
+  }
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg)
+    if (nok && offs[reg] >= 0) a.out[(size_t)offs[reg] * a.out_cs + n] = rs[reg];
+  if (a.stat_part) {
+    float s1 = 0.f, cnt = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg)
+      if (offs[reg] >= 0) { s1 += rs[reg]; cnt += 1.f; }
+    s1 += __shfl_xor(s1, 32);
+    cnt += __shfl_xor(cnt, 32);
+    const float mean = cnt > 0.f ? s1 / cnt : 0.f;
+    float q = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg)
+      if (offs[reg] >= 0) { const float dd = rs[reg] - mean; q += dd * dd; }
+    q += __shfl_xor(q, 32);
+    if (hh == 0 && nok && b0 < a.B) {
+      float *sp2 = a.stat_part + (((size_t)b0 * a.stat_ns + slot) * a.stat_C + n) * 2;
+      sp2[0] = mean;
+      sp2[1] = q;
+    }
+    if (lane == 0 && n == 0 && b0 < a.B) a.stat_cnt[(size_t)b0 * a.stat_ns + slot] = cnt;
+  }
+}
+
+// Fused 1x1x1 skip convolution (ResnetBlock.match_input, layers.py:46,74; inference plan) on a finished sub-block:
+// operand loads of up to SKB 32-channel chunks starting at chunk c0s (A: the RAW block input at this wave's 32 output
+// voxels, B: the packed 1x1 weights), and the MFMAs over them.
+constexpr int WINO_SKB = 3;                  // 32-channel chunks per batch (full-resolution skips have 2 or 3)
+__device__ __forceinline__ void wino_skip_load(const ConvArgs &a, int nt, int n2a, int n2, int c0s, int svox, int lane,
+                                               f32x4 (&sa)[WINO_SKB][4], f32x4 (&sw)[WINO_SKB][4]) {
+  const int hh = lane >> 5;
+  const f32x4 *w2 = reinterpret_cast<const f32x4 *>(a.s2w) + (size_t)nt * n2 * 4 * 64 + lane;
+#pragma unroll
+  for (int u = 0; u < WINO_SKB; ++u) {
+    const int c2 = c0s + u < n2 ? c0s + u : n2 - 1;
+    const float *s2 = c2 < n2a ? a.s2src0 + (size_t)svox * a.s2C0 + c2 * 32 : a.s2src1 + (size_t)svox * a.s2C1 + (c2 - n2a) * 32;
+#pragma unroll
+    for (int k8 = 0; k8 < 4; ++k8) {
+      sa[u][k8] = *reinterpret_cast<const f32x4 *>(s2 + 8 * k8 + 4 * hh);
+      sw[u][k8] = w2[(size_t)(c2 * 4 + k8) * 64];
+    }
+  }
+}
+__device__ __forceinline__ void wino_skip_mfma(int n2, int c0s, const f32x4 (&sa)[WINO_SKB][4], const f32x4 (&sw)[WINO_SKB][4], f32x16 &v) {
+#pragma unroll
+  for (int u = 0; u < WINO_SKB; ++u)
+    if (c0s + u < n2) {
+#pragma unroll
+      for (int k8 = 0; k8 < 4; ++k8)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) v = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[u][k8][jj], sw[u][k8][jj], v, 0, 0, 0);
+    }
+}
+
 // Tile = BZ planes x PY x PX patches (2x2 outputs each), ROWS = BZ * PY * PX <= 32 rows of the accumulator block
 // (rows beyond ROWS are padding).  Where the patch grid is not a multiple of PY / PX the LAST tile of a row is
 // shifted back inside the grid; it recomputes a few patches of its neighbour but owns (stores, counts in the
@@ -303,24 +385,13 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
   // ---- fused 1x1x1 skip convolution (ResnetBlock.match_input, layers.py:46,74; inference plan): issue the loads
   // of its operands now -- the RAW block input at this wave's 32 output voxels and the packed 1x1 weights -- so
   // that their latency hides behind the output transform; the MFMAs run on the finished sub-block below.
-  constexpr int SKB = 3;                     // 32-channel chunks per batch (full-resolution skips have 2 or 3)
   const int n2a = a.s2C0 >> 5, n2 = a.s2w ? (a.s2C0 + a.s2C1) >> 5 : 0;
-  f32x4 sa[SKB][4], sw[SKB][4];
+  f32x4 sa[WINO_SKB][4], sw[WINO_SKB][4];
   int svox = 0;
   if (n2 > 0) {                              // wave-uniform
     const int o = outoff[wave * 32 + r];     // A operand: lane = (row r, k half hh)
     svox = o >= 0 ? o : 0;
-    const f32x4 *w2 = reinterpret_cast<const f32x4 *>(a.s2w) + (size_t)nt * n2 * 4 * 64 + lane;
-#pragma unroll
-    for (int u = 0; u < SKB; ++u) {
-      const int c2 = u < n2 ? u : n2 - 1;
-      const float *s2 = c2 < n2a ? a.s2src0 + (size_t)svox * a.s2C0 + c2 * 32 : a.s2src1 + (size_t)svox * a.s2C1 + (c2 - n2a) * 32;
-#pragma unroll
-      for (int k8 = 0; k8 < 4; ++k8) {
-        sa[u][k8] = *reinterpret_cast<const f32x4 *>(s2 + 8 * k8 + 4 * hh);
-        sw[u][k8] = w2[(size_t)(c2 * 4 + k8) * 64];
-      }
-    }
+    wino_skip_load(a, nt, n2a, n2, 0, svox, lane, sa, sw);
   }
   // ---- output transform: A^T = (1,1,1,0), (0,1,-1,-1) along x in registers, along y through LDS -----------
   f32x16 t0 = acc[0] + acc[1] + acc[2];
@@ -345,77 +416,12 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
     }
   }
   if (n2 > 0) {
-    for (int c0s = 0; c0s < n2; c0s += SKB) {
-      if (c0s > 0) {                          // further batches (more than SKB chunks): loaded here, latency exposed
-        const f32x4 *w2 = reinterpret_cast<const f32x4 *>(a.s2w) + (size_t)nt * n2 * 4 * 64 + lane;
-#pragma unroll
-        for (int u = 0; u < SKB; ++u) {
-          const int c2 = c0s + u < n2 ? c0s + u : n2 - 1;
-          const float *s2 = c2 < n2a ? a.s2src0 + (size_t)svox * a.s2C0 + c2 * 32 : a.s2src1 + (size_t)svox * a.s2C1 + (c2 - n2a) * 32;
-#pragma unroll
-          for (int k8 = 0; k8 < 4; ++k8) {
-            sa[u][k8] = *reinterpret_cast<const f32x4 *>(s2 + 8 * k8 + 4 * hh);
-            sw[u][k8] = w2[(size_t)(c2 * 4 + k8) * 64];
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < SKB; ++u)
-        if (c0s + u < n2) {
-#pragma unroll
-          for (int k8 = 0; k8 < 4; ++k8)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) v = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[u][k8][jj], sw[u][k8][jj], v, 0, 0, 0);
-        }
+    for (int c0s = 0; c0s < n2; c0s += WINO_SKB) {
+      if (c0s > 0) wino_skip_load(a, nt, n2a, n2, c0s, svox, lane, sa, sw);   // further batches: latency exposed
+      wino_skip_mfma(n2, c0s, sa, sw, v);
     }
   }
-  // ---- epilogue of the 32-voxel x 32-channel sub-block (same arithmetic as the direct kernel's) ------------
-  const int n = nt * 32 + r;
-  const bool nok = n < a.Co;
-  const int nc = nok ? n : 0;
-  const float bias = a.bias[nc];
-  int offs[16];
-  float rs[16];
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) offs[reg] = outoff[wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh];
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) rs[reg] = v[reg] + bias;
-  if (a.temb) {
-    const float tv = a.temb[(size_t)a.tidx[bs] * a.temb_stride + nc];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) rs[reg] += tv;
-  }
-  if (a.resid) {
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int oc = offs[reg] >= 0 ? offs[reg] : 0;
-      rs[reg] += a.resid[(size_t)oc * a.res_cs + nc];
-    }
-  }
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg)
-    if (nok && offs[reg] >= 0) a.out[(size_t)offs[reg] * a.out_cs + n] = rs[reg];
-  if (a.stat_part) {
-    float s1 = 0.f, cnt = 0.f;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg)
-      if (offs[reg] >= 0) { s1 += rs[reg]; cnt += 1.f; }
-    s1 += __shfl_xor(s1, 32);
-    cnt += __shfl_xor(cnt, 32);
-    const float mean = cnt > 0.f ? s1 / cnt : 0.f;
-    float q = 0.f;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg)
-      if (offs[reg] >= 0) { const float dd = rs[reg] - mean; q += dd * dd; }
-    q += __shfl_xor(q, 32);
-    const int slot = (((tz * a.nty + ty) * a.ntx) + tx) * 4 + wave;
-    if (hh == 0 && nok && b0 < a.B) {
-      float *sp2 = a.stat_part + (((size_t)b0 * a.stat_ns + slot) * a.stat_C + n) * 2;
-      sp2[0] = mean;
-      sp2[1] = q;
-    }
-    if (lane == 0 && n == 0 && b0 < a.B) a.stat_cnt[(size_t)b0 * a.stat_ns + slot] = cnt;
-  }
+  wino_epilogue(a, v, outoff, nt, wave, lane, b0, bs, (((tz * a.nty + ty) * a.ntx) + tx) * 4 + wave);
 }
 
 // instantiated tiles (bz planes, by / 2 x bx / 2 patches): full resolution 8 x 2 x 2 (32 rows), half resolution of the

@@ -158,7 +158,8 @@ struct cm_model {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};  // extra lanes of the batch interleave
-  hipEvent_t ev_join[4] = {nullptr, nullptr, nullptr, nullptr}, ev_fork = nullptr;
+  hipEvent_t ev_join[4] = {nullptr, nullptr, nullptr, nullptr}, ev_fork = nullptr, ev_half = nullptr;
+  int mid_at = -1;          // run_ops records ev_half after this op (once): the second lane starts half a step late
   std::vector<Param> params;
   std::map<std::string, int> pindex;
   std::vector<BlockDesc> enc, bott, dec;
@@ -1261,6 +1262,10 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
       CM_HIP(hipEventRecord(e1, st));
       m->prof_events.push_back({(int)oi, {e0, e1}});
     }
+    if (m->mid_at >= 0 && (int)oi >= m->mid_at) {
+      CM_HIP(hipEventRecord(m->ev_half, st));
+      m->mid_at = -1;
+    }
     if (m->fin_done) oi = fin_at;   // (the ops in between are the ones this mode skips anyway)
     m->fin_next = nullptr; m->fin_done = false;
   }
@@ -1446,6 +1451,7 @@ int cm_model_create(const cm_unet_config *cfg, cm_model **out) {
     CM_HIP(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
   }
   CM_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+  CM_HIP(hipEventCreateWithFlags(&m->ev_half, hipEventDisableTiming));
   *out = m.release();
   return 0;
 }
@@ -1462,6 +1468,7 @@ int cm_model_destroy(cm_model *m) {
     if (m->ev_join[i]) hipEventDestroy(m->ev_join[i]);
   }
   if (m->ev_fork) hipEventDestroy(m->ev_fork);
+  if (m->ev_half) hipEventDestroy(m->ev_half);
   if (m->train) cm_free_train_state(m->train);
   delete m;
   return 0;
@@ -1844,6 +1851,12 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
       const int b0 = off[ln], Bn = Bl[ln];
       hipStream_t ls = sts[ln];
       if (k == 0) CM_HIP(cm::launch_fill_t(m->tbuf + b0, Bn, t, ls));
+      // two lanes (CM_LANES=2): optionally start the second one when the first is part-way through its first step
+      static const double lane_phase = getenv("CM_LANE_PHASE") ? atof(getenv("CM_LANE_PHASE")) : 0.0;   // measured: no offset is best (1.909 ms vs 1.916 / 1.920 / 1.941 at 0.3 / 0.5 / 0.7)
+      if (k == 0 && lanes == 2 && lane_phase > 0) {
+        if (ln == 0) m->mid_at = (int)(lane_phase * (double)m->ops.size());
+        else CM_HIP(hipStreamWaitEvent(ls, m->ev_half, 0));
+      }
       if (run_ops(m, Bn, ls, b0, ln)) return 1;
       cm::StepArgs al = a;
       al.B = Bn;
