@@ -67,6 +67,8 @@ struct ConvArgs {
   float *dbg_buf;      // cycle-stamp sink of the diagnostic build paths
   int stagger;         // start delay (in 64-cycle units) applied to every other first-wave workgroup
   int f16;             // 1: wfrag holds f16 fragments (4 halves per lane and step); specialised parity form only
+  int zsplit;          // weight gradient of a 27-tap layer on a two-plane grid: mtab rows [0,32) are plane 0, [32,64) plane 1,
+                       //   and a row block skips the z tap that multiplies its padding plane (18 of 27 taps, as the forward)
 };
 // does launch_conv have an f16-operand instantiation for this parity-form tile?
 bool conv_par_f16_variant(int MB, int NB, int bz, int by, int bx);
@@ -201,6 +203,10 @@ hipError_t launch_fill_t(long long *t, int B, long long value, hipStream_t st);
 hipError_t launch_count_nonfinite(const float *x, long long n, int *count, hipStream_t st);
 // graph replay: ++*kctr, then t[0..B) = tab[*kctr].t  (one workgroup)
 hipError_t launch_step_begin(long long *t, int B, const StepRow *tab, int *kctr, hipStream_t st);
+// Deferred per-parameter batch reductions of the backward pass (bias, GroupNorm gamma / beta gradients): one launch
+// for the whole job table instead of one ~5 us launch each.  out[c] = sum_b in[b * stride + c], fixed order.
+struct BsumJob { const float *in; float *out; int C, stride; };
+hipError_t launch_batch_sum_jobs(const BsumJob *jobs, int njobs, int B, int maxC, hipStream_t st);
 // mean((a-b)^2) over n elements -> *loss (single workgroup partials + deterministic final sum)
 hipError_t launch_mse_loss(const float *a, const float *b, long long n, float *partial, float *loss, hipStream_t st);
 // Dropout3d keep-mask / (1-p) per (sample, channel) from the device Philox stream

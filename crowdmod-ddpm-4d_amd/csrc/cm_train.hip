@@ -23,6 +23,7 @@ __device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rc
 //   A operand = dy[m][co] (lane: co = l&31, k = l>>5),  B operand = a[m+tap][ci].
 // Partials go to part[g][cb][kb][tap][32][32]; wgrad_reduce sums them in order.
 // --------------------------------------------------------------------------------
+template <bool ZS>
 __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const float *__restrict__ dy, int dy_cs,
                                                     float *__restrict__ part, int G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
   const int HZ = (a.bz - 1) * a.stride + td, HY = (a.by - 1) * a.stride + td, HX = (a.bx - 1) * a.stride + td;
   const int HV = HZ * HY * HX;
   const int nbox = a.bz * a.by * a.bx;
-  const int TM = (nbox + 31) & ~31;
+  const int TM = ZS ? 64 : (nbox + 31) & ~31;   // z-split: one 32-row block per plane
   const int ntile = a.nts * a.ntz * a.nty * a.ntx;
   const int Ctot = a.C0 + a.C1;
 
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
 
   for (int m = tid; m < TM; m += 256) {
     int hv = 0;
-    const int pk = m < nbox ? a.mtab[m] : -1;
+    const int pk = (m < nbox || ZS) ? a.mtab[m] : -1;
     if (pk >= 0) hv = ((((pk >> 18) & 255) * a.stride) * HY + ((pk >> 9) & 511) * a.stride) * HX + (pk & 511) * a.stride;
     rowhv[m] = hv;
   }
@@ -58,7 +59,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
   // straddles the concat boundary: C0 is a multiple of 8)
   const int ci0 = kb * 32;
   const int ntaps = a.ntaps;
-  constexpr int TW = 7;                       // taps per wave (27 = 7+7+7+6)
+  // taps per wave: 27 = 7+7+7+6 (tap t = wave + 4 ti); z-split: slot ti = 3 dz + k holds in-plane tap q = wave + 4 k
+  // (k < 2) of z tap dz, slot k = 2 the ninth in-plane tap (q = 8) on wave dz only -- the z tap of a slot is then the
+  // same on every wave and the skipped ones drop out at compile time
+  constexpr int TW = ZS ? 9 : 7;
   f32x16 acc[TW];
 #pragma unroll
   for (int i = 0; i < TW; ++i)
@@ -71,7 +75,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
   int tapoff[TW];
 #pragma unroll
   for (int ti = 0; ti < TW; ++ti) {
-    const int t = vsplit ? 0 : min(wave + 4 * ti, ntaps - 1);
+    int t = vsplit ? 0 : min(wave + 4 * ti, ntaps - 1);
+    if constexpr (ZS) t = (ti / 3) * 9 + ((ti % 3) < 2 ? wave + 4 * (ti % 3) : 8);
     const int dz = t / (td * td), rem = t - dz * td * td, dyy = rem / td, dx = rem - dyy * td;
     tapoff[ti] = ((dz * HY + dyy) * HX + dx) * 32;
   }
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
     // rows of this tile
     for (int m = tid; m < TM; m += 256) {
       int off = -1;
-      const int pk = m < nbox ? a.mtab[m] : -1;
+      const int pk = (m < nbox || ZS) ? a.mtab[m] : -1;
       if (pk >= 0) {
         const int oz = os * (z0 + ((pk >> 18) & 255)) + pz, oy = os * (y0 + ((pk >> 9) & 511)) + py, ox = os * (x0 + (pk & 511)) + px;
         if (oz < a.Zo && oy < a.Yo && ox < a.Xo) off = ((b * a.Zo + oz) * a.Yo + oy) * a.Xo + ox;
@@ -142,6 +147,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
       }
       continue;
     }
+    if constexpr (ZS) {
+      // rows [0,32) lie in plane 0 (their dz = 0 taps read the padding plane: exact zeros, skipped), [32,64) in plane 1
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int dzs = half == 0 ? 1 : 0;    // the two z taps this plane uses: dzs, dzs + 1
+        const bool x0 = wave == dzs, x1 = wave == dzs + 1;   // this wave holds the ninth in-plane tap of that z tap
+#pragma unroll 2
+        for (int m0 = 32 * half; m0 < 32 * half + 32; m0 += 2) {
+          const float av = dyt[(m0 + h) * 32 + r];
+          const int hb = rowhv[m0 + h] * 32 + r;
+          const float b00 = at[hb + tapoff[3 * dzs]], b01 = at[hb + tapoff[3 * dzs + 1]];
+          const float b10 = at[hb + tapoff[3 * dzs + 3]], b11 = at[hb + tapoff[3 * dzs + 4]];
+          acc[3 * dzs] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b00, acc[3 * dzs], 0, 0, 0);
+          acc[3 * dzs + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b01, acc[3 * dzs + 1], 0, 0, 0);
+          acc[3 * dzs + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b10, acc[3 * dzs + 3], 0, 0, 0);
+          acc[3 * dzs + 4] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b11, acc[3 * dzs + 4], 0, 0, 0);
+          if (x0) acc[3 * dzs + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, at[hb + tapoff[3 * dzs + 2]], acc[3 * dzs + 2], 0, 0, 0);
+          if (x1) acc[3 * dzs + 5] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, at[hb + tapoff[3 * dzs + 5]], acc[3 * dzs + 5], 0, 0, 0);
+        }
+      }
+      continue;
+    }
 #pragma unroll 2
     for (int m0 = 0; m0 < TM; m0 += 2) {
       const float av = dyt[(m0 + h) * 32 + r];
@@ -165,7 +192,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ConvArgs a, const floa
   }
 #pragma unroll
   for (int ti = 0; ti < TW; ++ti) {
-    const int t = wave + 4 * ti;
+    int t = wave + 4 * ti;
+    if constexpr (ZS) t = (ti % 3) < 2 ? (ti / 3) * 9 + wave + 4 * (ti % 3) : (wave == ti / 3 ? (ti / 3) * 9 + 8 : ntaps);
     if (t < ntaps) {
       float *p = part + ((((size_t)blockIdx.x * gridDim.y + cb) * gridDim.z + kb) * ntaps + t) * 1024;
 #pragma unroll
@@ -181,21 +209,25 @@ hipError_t launch_wgrad(const ConvArgs &a, int MB, const float *dy, int dy_cs, f
                         hipStream_t st) {
   if (a.bs != 1 || (a.par && (a.td != 2 || a.ntaps != 8 || a.stride != 1 || a.ups))) return hipErrorInvalidValue;
   const int HV = ((a.bz - 1) * a.stride + a.td) * ((a.by - 1) * a.stride + a.td) * ((a.bx - 1) * a.stride + a.td);
-  const int TM = 32 * MB;
+  const int TM = a.zsplit ? 64 : 32 * MB;
+  if (a.zsplit && (a.bz != 2 || a.by * a.bx > 32 || a.ntaps != 27 || a.stride != 1 || a.Zo != 2 || a.Zs != 2 || a.par || a.ups)) return hipErrorInvalidValue;
   const size_t lds = ((size_t)2 * TM + (size_t)TM * 32 + (size_t)HV * 32) * 4;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static bool attr_set[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!attr_set[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev & 63] = true;
   }
   ConvArgs aa = a;
   aa.dbg = conv_dbg_flags();
-  hipLaunchKernelGGL(wgrad_kernel, dim3(a.par ? G * 8 : G, ncb, nkb), dim3(256), lds, st, aa, dy, dy_cs, part, G);
+  if (a.zsplit) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(G, ncb, nkb), dim3(256), lds, st, aa, dy, dy_cs, part, G);
+  else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.par ? G * 8 : G, ncb, nkb), dim3(256), lds, st, aa, dy, dy_cs, part, G);
   return hipGetLastError();
 }
 
@@ -356,6 +388,30 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float *__restrict_
     for (int l = 0; l < 8; ++l) t += sh[l * 32 + tid];
     out[c] = accumulate ? out[c] + t : t;
   }
+}
+
+__global__ __launch_bounds__(256) void batch_sum_jobs_kernel(const BsumJob *__restrict__ jobs, int B) {
+  __shared__ float sh[256];
+  const BsumJob j = jobs[blockIdx.y];
+  if ((int)blockIdx.x * 32 >= j.C) return;    // (workgroup-uniform)
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x * 32 + (tid & 31), bl = tid >> 5;
+  float s = 0.f;
+  if (c < j.C)
+    for (int b = bl; b < B; b += 8) s += j.in[(size_t)b * j.stride + c];
+  sh[tid] = s;
+  __syncthreads();
+  if (tid < 32 && c < j.C) {
+    float t = 0.f;
+    for (int l = 0; l < 8; ++l) t += sh[l * 32 + tid];
+    j.out[c] = t;
+  }
+}
+
+hipError_t launch_batch_sum_jobs(const BsumJob *jobs, int njobs, int B, int maxC, hipStream_t st) {
+  if (njobs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(batch_sum_jobs_kernel, dim3((maxC + 31) / 32, njobs), dim3(256), 0, st, jobs, B);
+  return hipGetLastError();
 }
 
 hipError_t launch_batch_sum(const float *in, int B, int C, int stride, float *out, int accumulate, hipStream_t st) {
