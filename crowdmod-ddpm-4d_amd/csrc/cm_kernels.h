@@ -203,6 +203,26 @@ hipError_t launch_fill_t(long long *t, int B, long long value, hipStream_t st);
 hipError_t launch_count_nonfinite(const float *x, long long n, int *count, hipStream_t st);
 // graph replay: ++*kctr, then t[0..B) = tab[*kctr].t  (one workgroup)
 hipError_t launch_step_begin(long long *t, int B, const StepRow *tab, int *kctr, hipStream_t st);
+// Weight gradient of a 3x3x3 stride-1 conv with FEW channels on one side (the UNet's first conv: 8-channel input;
+// its last conv: 3-4 output channels).  The generic kernel spends a 32x32 MFMA block per tap on them with 4-8x
+// padding; here the narrow side is packed with the taps into the N dimension:
+//   dW[co][ci][tap] = sum_v dY[v][co] A[v + tap][ci]
+//   first conv (mirror 0): rows = co from dY at v (wide, unshifted), columns (tap, ci) from A at v + tap - 1
+//   last conv  (mirror 1): rows = ci from A at u (wide, GroupNorm + SiLU applied on load), columns (tap, co) from dY at u - tap + 1
+// NBLK = ceil(27 * CN / 32) MFMA blocks per voxel pair instead of 27.  Partials part[G][NBLK][32][32] (the four waves of a workgroup are summed in wave order before the store).
+struct WgradPackArgs {
+  const float *wide; int wide_cs;       // [B][Z][Y][X][wide_cs], channels [0, 32)
+  const float *gn; int silu;            // [B][2][32] scale / shift rows of the wide tensor, or null
+  const float *narrow; int narrow_cs;   // [B][Z][Y][X][narrow_cs], channels [0, cn_valid)
+  int cn_valid, mirror;
+  int B, Z, Y, X;
+  int bz, by, bx, ntz, nty, ntx;        // tile box (bz * by * bx <= 256 rows, even) and tiles per sample
+  float *part;
+};
+hipError_t launch_wgrad_pack(const WgradPackArgs &a, int CN, int G, hipStream_t st);
+// part -> dW[Co][Ci][27] (reference layout): mirror 0: Co = 32 rows, Ci = cn_valid; mirror 1: Ci = 32 rows, Co = cn_valid
+hipError_t launch_wgrad_pack_reduce(const float *part, int G, int CN, int cn_valid, int mirror, int Co, int Ci, float *dW, hipStream_t st);
+
 // Deferred per-parameter batch reductions of the backward pass (bias, GroupNorm gamma / beta gradients): one launch
 // for the whole job table instead of one ~5 us launch each.  out[c] = sum_b in[b * stride + c], fixed order.
 struct BsumJob { const float *in; float *out; int C, stride; };

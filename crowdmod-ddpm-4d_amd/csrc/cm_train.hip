@@ -231,6 +231,151 @@ hipError_t launch_wgrad(const ConvArgs &a, int MB, const float *dy, int dy_cs, f
   return hipGetLastError();
 }
 
+// --------------------------------------------------------------------------------
+// Packed-column weight gradient (see WgradPackArgs): the four waves split the voxel pairs of a tile, each keeps all
+// NBLK accumulator blocks; a lane's column (tap, narrow channel) is a fixed offset into the staged narrow halo.
+// --------------------------------------------------------------------------------
+template <int CN>
+__global__ __launch_bounds__(256) void wgrad_pack_kernel(const WgradPackArgs a, int G) {
+  constexpr int NBLK = (27 * CN + 31) / 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int HZ = a.bz + 2, HY = a.by + 2, HX = a.bx + 2, HV = HZ * HY * HX;
+  const int TM = a.bz * a.by * a.bx;
+  int *rowhv = reinterpret_cast<int *>(lds);   // [TM] halo index of a row's own voxel at tap (0,0,0)
+  float *wt = lds + ((TM + 3) & ~3);           // [TM][32]
+  float *nt = wt + TM * 32;                    // [HV][CN]
+  for (int m = tid; m < TM; m += 256) {
+    const int x = m % a.bx, q = m / a.bx, y = q % a.by, z = q / a.by;
+    rowhv[m] = ((z * HY + y) * HX + x) * CN;
+  }
+  int coloff[NBLK];
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    const int col = blk * 32 + r, tap = col / CN, ch = col - tap * CN;
+    int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+    if (a.mirror) { dz = 2 - dz; dy = 2 - dy; dx = 2 - dx; }
+    coloff[blk] = tap < 27 ? ((dz * HY + dy) * HX + dx) * CN + ch : 0;   // (columns beyond 27 taps: ignored by the reduce)
+  }
+  f32x16 acc[NBLK];
+#pragma unroll
+  for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  const int ntile = a.B * a.ntz * a.nty * a.ntx;
+  for (int tile = blockIdx.x; tile < ntile; tile += G) {
+    int tt = tile;
+    const int tx = tt % a.ntx; tt /= a.ntx;
+    const int ty = tt % a.nty; tt /= a.nty;
+    const int tz = tt % a.ntz;
+    const int b = tt / a.ntz;
+    const int z0 = tz * a.bz, y0 = ty * a.by, x0 = tx * a.bx;
+    __syncthreads();                           // previous tile consumed (and rowhv written)
+    // wide rows (activation recomputed as the forward stages it)
+    for (int i = tid; i < TM * 8; i += 256) {
+      const int m = i >> 3, q = i & 7;
+      const int x = m % a.bx, qq = m / a.bx, y = qq % a.by, z = qq / a.by;
+      const int cz = z0 + z, cy = y0 + y, cx = x0 + x;
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (cz < a.Z && cy < a.Y && cx < a.X) {
+        w = *reinterpret_cast<const f32x4 *>(a.wide + ((((size_t)b * a.Z + cz) * a.Y + cy) * a.X + cx) * a.wide_cs + 4 * q);
+        if (a.gn) {
+          const float *gp = a.gn + (size_t)b * 64 + 4 * q;
+          w = w * *reinterpret_cast<const f32x4 *>(gp) + *reinterpret_cast<const f32x4 *>(gp + 32);
+          if (a.silu) { w[0] *= sigmoid_f(w[0]); w[1] *= sigmoid_f(w[1]); w[2] *= sigmoid_f(w[2]); w[3] *= sigmoid_f(w[3]); }
+        }
+      }
+      *reinterpret_cast<f32x4 *>(&wt[m * 32 + 4 * q]) = w;
+    }
+    // narrow halo (zero outside the grid = the conv's zero padding, and beyond the valid channels)
+    for (int i = tid; i < HV * (CN / 4); i += 256) {
+      const int hv = i / (CN / 4), q = i - hv * (CN / 4);
+      const int hx = hv % HX, qq = hv / HX, hy = qq % HY, hz = qq / HY;
+      const int cz = z0 + hz - 1, cy = y0 + hy - 1, cx = x0 + hx - 1;
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (cz >= 0 && cz < a.Z && cy >= 0 && cy < a.Y && cx >= 0 && cx < a.X) {
+        const float *p = a.narrow + ((((size_t)b * a.Z + cz) * a.Y + cy) * a.X + cx) * a.narrow_cs + 4 * q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = 4 * q + e < a.cn_valid ? p[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4 *>(&nt[hv * CN + 4 * q]) = w;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int m0 = 2 * wave; m0 < TM; m0 += 8) {
+      const float av = wt[(m0 + h) * 32 + r];
+      const int hb = rowhv[m0 + h];
+      float bv[NBLK];
+#pragma unroll
+      for (int blk = 0; blk < NBLK; ++blk) bv[blk] = nt[hb + coloff[blk]];
+#pragma unroll
+      for (int blk = 0; blk < NBLK; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[blk], acc[blk], 0, 0, 0);
+    }
+  }
+  // cross-wave sum through LDS, block by block, in wave order (the staging buffers are dead); wave 0 stores
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) lds[((wave - 1) * 16 + reg) * 64 + lane] = acc[blk][reg];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      float *p = a.part + ((size_t)blockIdx.x * NBLK + blk) * 1024;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        float v = acc[blk][reg];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) v += lds[(w * 16 + reg) * 64 + lane];
+        p[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 32 + r] = v;
+      }
+    }
+  }
+}
+
+hipError_t launch_wgrad_pack(const WgradPackArgs &a, int CN, int G, hipStream_t st) {
+  const int TM = a.bz * a.by * a.bx, HV = (a.bz + 2) * (a.by + 2) * (a.bx + 2);
+  if (TM > 256 || (TM & 1) || (CN != 4 && CN != 8) || a.cn_valid > CN || G < 1) return hipErrorInvalidValue;
+  const size_t lds = std::max<size_t>(((size_t)((TM + 3) & ~3) + (size_t)TM * 32 + (size_t)HV * CN) * 4, (size_t)3 * 1024 * 4);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  if (CN == 4) hipLaunchKernelGGL(wgrad_pack_kernel<4>, dim3(G), dim3(256), lds, st, a, G);
+  else hipLaunchKernelGGL(wgrad_pack_kernel<8>, dim3(G), dim3(256), lds, st, a, G);
+  return hipGetLastError();
+}
+
+// Threads walk the partial layout (column fastest, coalesced); four lanes per element take the partials
+// p = lane, lane + 4, ... and are merged in lane order: a fixed summation order.  Internal tap (dz,dy,dx) =
+// reference [kH=dy][kW=dx][kL=dz] as in wgrad_reduce_kernel.
+__global__ __launch_bounds__(256) void wgrad_pack_reduce_kernel(const float *__restrict__ part, int G, int CN, int cn_valid, int mirror,
+                                                                int Co, int Ci, float *__restrict__ dW) {
+  __shared__ float sh[256];
+  const int NBLK = (27 * CN + 31) / 32;
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), gl = threadIdx.x >> 6;
+  const int total = NBLK * 1024;
+  float s = 0.f;
+  if (e < total)
+    for (int p = gl; p < G; p += 4) s += part[(size_t)p * total + e];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (gl != 0 || e >= total) return;
+  const float t = ((sh[threadIdx.x] + sh[threadIdx.x + 64]) + sh[threadIdx.x + 128]) + sh[threadIdx.x + 192];
+  const int blk = e >> 10, i = (e >> 5) & 31, j = e & 31;
+  const int col = blk * 32 + j, tap = col / CN, ch = col - tap * CN;
+  if (tap >= 27 || ch >= cn_valid) return;
+  const int co = mirror ? ch : i, ci = mirror ? i : ch;
+  const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+  if (co < Co && ci < Ci) dW[((size_t)co * Ci + ci) * 27 + (dy * 3 + dx) * 3 + dz] = t;
+}
+
+hipError_t launch_wgrad_pack_reduce(const float *part, int G, int CN, int cn_valid, int mirror, int Co, int Ci, float *dW, hipStream_t st) {
+  const int total = ((27 * CN + 31) / 32) * 1024;
+  hipLaunchKernelGGL(wgrad_pack_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, part, G, CN, cn_valid, mirror, Co, Ci, dW);
+  return hipGetLastError();
+}
+
 // Parity-form partials part[g * 8 + p][cb][kb][e (8)][32 co][32 ci] -> dW[co][ci][27 taps] (reference layout):
 // the forward's parity weights are W_p[e] = sum of the taps d that land on source offset e for parity p, so
 // dW[d] = sum_p dW_p[e(p, d)]  with  e = emap(p_axis, d_axis) per axis:  p = 0: d0 -> 0, d1,d2 -> 1;  p = 1: d0,d1 -> 0, d2 -> 1.
@@ -664,41 +809,52 @@ hipError_t launch_mse_grad(const float *pred, const float *target, float *g, int
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ dO,
                                                        float *__restrict__ dqkv, int S, int E) {
-  extern __shared__ float sm[];  // Q[S][D] K[S][D] V[S][D] dO[S][D] P[S][S] dS[S][S]
-  float *Q = sm, *K = Q + S * D, *Vv = K + S * D, *dOs = Vv + S * D, *Pm = dOs + S * D, *dSm = Pm + S * S;
+  // Q K V dO [S][D + 1] (odd row stride: a lane per key row reads conflict-free), P [S][S], dS [S][S]
+  constexpr int DP = D + 1;
+  extern __shared__ float sm[];
+  float *Q = sm, *K = Q + S * DP, *Vv = K + S * DP, *dOs = Vv + S * DP, *Pm = dOs + S * DP, *dSm = Pm + S * S;
   const int hd = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const float *base = qkv + (size_t)b * S * 3 * E;
   for (int i = tid; i < S * D; i += 256) {
     const int s = i / D, d = i % D;
-    Q[i] = base[(size_t)s * 3 * E + hd * D + d];
-    K[i] = base[(size_t)s * 3 * E + E + hd * D + d];
-    Vv[i] = base[(size_t)s * 3 * E + 2 * E + hd * D + d];
-    dOs[i] = dO[((size_t)b * S + s) * E + hd * D + d];
+    Q[s * DP + d] = base[(size_t)s * 3 * E + hd * D + d];
+    K[s * DP + d] = base[(size_t)s * 3 * E + E + hd * D + d];
+    Vv[s * DP + d] = base[(size_t)s * 3 * E + 2 * E + hd * D + d];
+    dOs[s * DP + d] = dO[((size_t)b * S + s) * E + hd * D + d];
   }
   __syncthreads();
   const float scale = rsqrtf((float)D);
-  for (int row = tid; row < S; row += 256) {
-    float mx = -3.0e38f;
-    for (int j = 0; j < S; ++j) {
-      float sc = 0.f;
-      for (int d = 0; d < D; ++d) sc = fmaf(Q[row * D + d], K[j * D + d], sc);
-      sc *= scale;
-      Pm[row * S + j] = sc;
-      mx = fmaxf(mx, sc);
+  // scores and dP = dO V^T, one (row, key) pair per thread and round
+  for (int idx = tid; idx < S * S; idx += 256) {
+    const int row = idx / S, j = idx - row * S;
+    float sc = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      sc = fmaf(Q[row * DP + d], K[j * DP + d], sc);
+      dp = fmaf(dOs[row * DP + d], Vv[j * DP + d], dp);
     }
+    Pm[idx] = sc * scale;
+    dSm[idx] = dp;
+  }
+  __syncthreads();
+  // row softmax and dS = P o (dP - rowsum(dP o P)): four adjacent lanes per row, merged by shuffles in a fixed order
+  for (int r0 = 0; r0 < S; r0 += 64) {
+    const int row = r0 + (tid >> 2), l4 = tid & 3;
+    const bool ok = row < S;
+    float mx = -3.0e38f;
+    if (ok) for (int j = l4; j < S; j += 4) mx = fmaxf(mx, Pm[row * S + j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1));
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
     float l = 0.f;
-    for (int j = 0; j < S; ++j) { const float p = __expf(Pm[row * S + j] - mx); Pm[row * S + j] = p; l += p; }
+    if (ok) for (int j = l4; j < S; j += 4) { const float p = __expf(Pm[row * S + j] - mx); Pm[row * S + j] = p; l += p; }
+    l += __shfl_xor(l, 1);
+    l += __shfl_xor(l, 2);
     const float inv = 1.0f / l;
     float dot = 0.f;
-    for (int j = 0; j < S; ++j) {
-      const float p = Pm[row * S + j] * inv;
-      Pm[row * S + j] = p;
-      float dp = 0.f;
-      for (int d = 0; d < D; ++d) dp = fmaf(dOs[row * D + d], Vv[j * D + d], dp);
-      dSm[row * S + j] = dp;
-      dot = fmaf(dp, p, dot);
-    }
-    for (int j = 0; j < S; ++j) dSm[row * S + j] = Pm[row * S + j] * (dSm[row * S + j] - dot);
+    if (ok) for (int j = l4; j < S; j += 4) { const float p = Pm[row * S + j] * inv; Pm[row * S + j] = p; dot = fmaf(dSm[row * S + j], p, dot); }
+    dot += __shfl_xor(dot, 1);
+    dot += __shfl_xor(dot, 2);
+    if (ok) for (int j = l4; j < S; j += 4) dSm[row * S + j] = Pm[row * S + j] * (dSm[row * S + j] - dot);
   }
   __syncthreads();
   float *ob = dqkv + (size_t)b * S * 3 * E;
@@ -706,9 +862,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__
     const int s = i / D, d = i % D;
     float dq = 0.f, dk = 0.f, dv = 0.f;
     for (int j = 0; j < S; ++j) {
-      dq = fmaf(dSm[s * S + j], K[j * D + d], dq);
-      dk = fmaf(dSm[j * S + s], Q[j * D + d], dk);
-      dv = fmaf(Pm[j * S + s], dOs[j * D + d], dv);
+      dq = fmaf(dSm[s * S + j], K[j * DP + d], dq);
+      dk = fmaf(dSm[j * S + s], Q[j * DP + d], dk);
+      dv = fmaf(Pm[j * S + s], dOs[j * DP + d], dv);
     }
     ob[(size_t)s * 3 * E + hd * D + d] = dq * scale;
     ob[(size_t)s * 3 * E + E + hd * D + d] = dk * scale;
@@ -718,7 +874,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__
 
 hipError_t launch_attn_bwd(const float *qkv, const float *dO, float *dqkv, int B, int S, int E, int heads, hipStream_t st) {
   const int D = E / heads;
-  const size_t smem = ((size_t)4 * S * D + (size_t)2 * S * S) * sizeof(float);
+  const size_t smem = ((size_t)4 * S * (D + 1) + (size_t)2 * S * S) * sizeof(float);
   if (smem > 160 * 1024) return hipErrorInvalidValue;
 #define CM_AB(DD)                                                                                         \
   if (D == DD) {                                                                                          \
