@@ -223,6 +223,13 @@ hipError_t launch_wgrad_pack(const WgradPackArgs &a, int CN, int G, hipStream_t 
 // part -> dW[Co][Ci][27] (reference layout): mirror 0: Co = 32 rows, Ci = cn_valid; mirror 1: Ci = 32 rows, Co = cn_valid
 hipError_t launch_wgrad_pack_reduce(const float *part, int G, int CN, int cn_valid, int mirror, int Co, int Ci, float *dW, hipStream_t st);
 
+// Weight gradient of a 1x1x1 stride-1 conv (skip convs, attention projections): dW[co][ci] = sum_n dy[n][co] a[n][ci] over
+// the flat row index n = (sample, voxel); a = the conv's actual input (concat, GroupNorm affine, SiLU, dropout multiplier
+// recomputed on load as in the forward).  One workgroup = 32 output channels x NKB 32-channel input blocks and a
+// strided set of 128-row chunks: every input row is read once per co block instead of once per (co, ci) block pair.
+// Partials part[G][ncb][nkb][32 co][32 ci] (waves summed in order before the store) -> launch_wgrad_reduce(ntaps 1, nvs 1).
+hipError_t launch_wgrad_1x1(const ConvArgs &a, const float *dy, int dy_cs, long long V, float *part, int G, int ncb, int nkb, int NKB, hipStream_t st);
+
 // Deferred per-parameter batch reductions of the backward pass (bias, GroupNorm gamma / beta gradients): one launch
 // for the whole job table instead of one ~5 us launch each.  out[c] = sum_b in[b * stride + c], fixed order.
 struct BsumJob { const float *in; float *out; int C, stride; };
@@ -244,7 +251,7 @@ hipError_t launch_cl_to_ref(const float *x_cl, int cs, float *out, int B, int C,
 hipError_t launch_wgrad(const ConvArgs &a, int MB, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb,
                         hipStream_t st);
 hipError_t launch_wgrad_reduce(const float *part, int G, int ncb, int nkb, int ntaps, int Co, int Ci, float *dW,
-                               hipStream_t st);
+                               hipStream_t st, int force_nvs = 0 /* 1: one partial per group even for ntaps == 1 */);
 // parity-form (upsample conv) partials [G * 8 parities][ncb][nkb][8][32][32] -> dW [Co][Ci][27] in reference layout
 hipError_t launch_wgrad_reduce_par(const float *part, int G, int ncb, int nkb, int Co, int Ci, float *dW, hipStream_t st);
 hipError_t launch_voxel_sum(const float *x, int B, int V, int C, int cs, float *out, int ostride,

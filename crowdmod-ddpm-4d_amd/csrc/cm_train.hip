@@ -232,6 +232,112 @@ hipError_t launch_wgrad(const ConvArgs &a, int MB, const float *dy, int dy_cs, f
 }
 
 // --------------------------------------------------------------------------------
+// 1x1x1 weight gradient over flat rows (see launch_wgrad_1x1).  grid (G, ncb, nkb / NKB).
+// --------------------------------------------------------------------------------
+template <int NKB>
+__global__ __launch_bounds__(256) void wgrad_1x1_kernel(const ConvArgs a, const float *__restrict__ dy, int dy_cs, long long V,
+                                                        float *__restrict__ part, int G, int nkb) {
+  constexpr int TM = 128, XS = 32 * NKB;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *dyt = lds;                 // [TM][32]
+  float *xt = lds + TM * 32;        // [TM][32 * NKB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int cb = blockIdx.y, kg = blockIdx.z;
+  const int Ctot = a.C0 + a.C1;
+  const long long N = (long long)a.B * V;
+  const long long nchunk = (N + TM - 1) / TM;
+  f32x16 acc[NKB];
+#pragma unroll
+  for (int i = 0; i < NKB; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  for (long long ch = blockIdx.x; ch < nchunk; ch += G) {
+    const long long n0 = ch * TM;
+    __syncthreads();
+    for (int i = tid; i < TM * 8; i += 256) {
+      const int m = i >> 3, q = i & 7;
+      const long long n = n0 + m;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n < N) {
+        const int co = cb * 32 + 4 * q;
+        const float *p = dy + (size_t)n * dy_cs + co;
+        if (co + 3 < a.Co) v = *reinterpret_cast<const f32x4 *>(p);
+        else { v[0] = co < a.Co ? p[0] : 0.f; v[1] = co + 1 < a.Co ? p[1] : 0.f; v[2] = co + 2 < a.Co ? p[2] : 0.f; }
+      }
+      *reinterpret_cast<f32x4 *>(&dyt[m * 32 + 4 * q]) = v;
+    }
+    for (int i = tid; i < TM * 8 * NKB; i += 256) {
+      const int m = i / (8 * NKB), q = i - m * (8 * NKB);
+      const long long n = n0 + m;
+      const int c = kg * XS + 4 * q;
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (n < N && c < Ctot) {
+        const int b = (int)(n / V);
+        w = (c < a.C0) ? *reinterpret_cast<const f32x4 *>(a.src0 + (size_t)n * a.C0 + c)
+                       : *reinterpret_cast<const f32x4 *>(a.src1 + (size_t)n * a.C1 + (c - a.C0));
+        if (a.gn) {
+          const float *gp = a.gn + (size_t)b * 2 * Ctot + c;
+          w = w * *reinterpret_cast<const f32x4 *>(gp) + *reinterpret_cast<const f32x4 *>(gp + Ctot);
+          if (a.silu) { w[0] *= sigmoid_f(w[0]); w[1] *= sigmoid_f(w[1]); w[2] *= sigmoid_f(w[2]); w[3] *= sigmoid_f(w[3]); }
+        }
+        if (a.pm) w = w * *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + c);
+      }
+      *reinterpret_cast<f32x4 *>(&xt[m * XS + 4 * q]) = w;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int m0 = 2 * wave; m0 < TM; m0 += 8) {
+      const float av = dyt[(m0 + h) * 32 + r];
+      float bv[NKB];
+#pragma unroll
+      for (int k = 0; k < NKB; ++k) bv[k] = xt[(m0 + h) * XS + k * 32 + r];
+#pragma unroll
+      for (int k = 0; k < NKB; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[k], acc[k], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NKB; ++k) {
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) lds[((wave - 1) * 16 + reg) * 64 + lane] = acc[k][reg];
+    }
+    __syncthreads();
+    const int kb = kg * NKB + k;
+    if (wave == 0 && kb < nkb) {
+      float *p = part + (((size_t)blockIdx.x * gridDim.y + cb) * nkb + kb) * 1024;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        float v = acc[k][reg];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) v += lds[(w * 16 + reg) * 64 + lane];
+        p[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 32 + r] = v;
+      }
+    }
+  }
+}
+
+hipError_t launch_wgrad_1x1(const ConvArgs &a, const float *dy, int dy_cs, long long V, float *part, int G, int ncb, int nkb, int NKB,
+                            hipStream_t st) {
+  if (a.ntaps != 1 || a.stride != 1 || a.par || a.ups || G < 1 || (a.C0 & 3) || (a.C1 & 3)) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)G, (unsigned)ncb, (unsigned)((nkb + NKB - 1) / NKB));
+  const size_t lds = (size_t)128 * 32 * (1 + NKB) * 4;
+#define CM_W1(K)                                                                                          \
+  if (NKB == K) {                                                                                         \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_1x1_kernel<K>),               \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
+    if (e != hipSuccess) return e;                                                                        \
+    hipLaunchKernelGGL((wgrad_1x1_kernel<K>), grid, dim3(256), lds, st, a, dy, dy_cs, V, part, G, nkb);    \
+    return hipGetLastError();                                                                             \
+  }
+  CM_W1(1) CM_W1(2) CM_W1(3) CM_W1(4)
+#undef CM_W1
+  return hipErrorInvalidValue;
+}
+
+// --------------------------------------------------------------------------------
 // Packed-column weight gradient (see WgradPackArgs): the four waves split the voxel pairs of a tile, each keeps all
 // NBLK accumulator blocks; a lane's column (tap, narrow channel) is a fixed offset into the staged narrow halo.
 // --------------------------------------------------------------------------------
@@ -456,9 +562,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 }
 
 hipError_t launch_wgrad_reduce(const float *part, int G, int ncb, int nkb, int ntaps, int Co, int Ci, float *dW,
-                               hipStream_t st) {
+                               hipStream_t st, int force_nvs) {
   const long long total = (long long)ncb * nkb * ntaps * 1024;
-  const int nvs = (ntaps == 1 && !(conv_dbg_flags() & 8192)) ? 4 : 1;   // per-wave partials of the 1x1x1 voxel split
+  const int nvs = force_nvs ? force_nvs : (ntaps == 1 && !(conv_dbg_flags() & 8192)) ? 4 : 1;   // per-wave partials of the 1x1x1 voxel split
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, G, ncb, nkb,
                      ntaps, Co, Ci, dW, nvs);
   return hipGetLastError();
