@@ -230,6 +230,13 @@ hipError_t launch_wgrad_pack_reduce(const float *part, int G, int CN, int cn_val
 // Partials part[G][ncb][nkb][32 co][32 ci] (waves summed in order before the store) -> launch_wgrad_reduce(ntaps 1, nvs 1).
 hipError_t launch_wgrad_1x1(const ConvArgs &a, const float *dy, int dy_cs, long long V, float *part, int G, int ncb, int nkb, int NKB, hipStream_t st);
 
+// Weight gradient of an upsample conv in the forward's parity form (cm_conv.hip): class p = (pz,py,px) reads dY at the
+// output voxels 2i + p and the LOW-resolution input at i + e + p - 1, e in {0,1}^3.  One workgroup = (tile group, class,
+// 32 co, 32 ci); its four waves split the voxel pairs and each keeps all 8 tap blocks (one dY fragment feeds 8 MFMAs).
+// Partials in launch_wgrad_reduce_par's layout [G * 8][ncb][nkb][8][32][32] (waves summed in order before the store).
+// Tile box (a.bz, a.by, a.bx) in low-resolution voxels, a.ntz/nty/ntx tiles per sample; a.gn / a.pm must be null.
+hipError_t launch_wgrad_par(const ConvArgs &a, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb, hipStream_t st);
+
 // Deferred per-parameter batch reductions of the backward pass (bias, GroupNorm gamma / beta gradients): one launch
 // for the whole job table instead of one ~5 us launch each.  out[c] = sum_b in[b * stride + c], fixed order.
 struct BsumJob { const float *in; float *out; int C, stride; };

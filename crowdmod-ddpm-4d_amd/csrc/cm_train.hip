@@ -232,6 +232,119 @@ hipError_t launch_wgrad(const ConvArgs &a, int MB, const float *dy, int dy_cs, f
 }
 
 // --------------------------------------------------------------------------------
+// Parity-form weight gradient of the upsample convs (see launch_wgrad_par).  grid (G * 8, ncb, nkb).
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_par_kernel(const ConvArgs a, const float *__restrict__ dy, int dy_cs,
+                                                        float *__restrict__ part, int G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int par = blockIdx.x & 7, g = blockIdx.x >> 3, cb = blockIdx.y, kb = blockIdx.z;
+  const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
+  const int HZ = a.bz + 1, HY = a.by + 1, HX = a.bx + 1, HV = HZ * HY * HX;
+  const int nbox = a.bz * a.by * a.bx, TM = (nbox + 1) & ~1;
+  int *rowhv = reinterpret_cast<int *>(lds);   // [TM] halo index (x 32) of a row's tap (0,0,0)
+  float *dyt = lds + ((TM + 3) & ~3);          // [TM][32]
+  float *at = dyt + TM * 32;                   // [HV][32]
+  for (int m = tid; m < TM; m += 256) {
+    const int mm = m < nbox ? m : 0;
+    const int x = mm % a.bx, q = mm / a.bx, y = q % a.by, z = q / a.by;
+    rowhv[m] = ((z * HY + y) * HX + x) * 32;
+  }
+  int tapoff[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) tapoff[e] = ((((e >> 2) & 1) * HY + ((e >> 1) & 1)) * HX + (e & 1)) * 32;
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  const int ntile = a.B * a.ntz * a.nty * a.ntx;
+  const int ci0 = kb * 32, Ctot = a.C0 + a.C1;
+  for (int tile = g; tile < ntile; tile += G) {
+    int tt = tile;
+    const int tx = tt % a.ntx; tt /= a.ntx;
+    const int ty = tt % a.nty; tt /= a.nty;
+    const int tz = tt % a.ntz;
+    const int b = tt / a.ntz;
+    const int z0 = tz * a.bz, y0 = ty * a.by, x0 = tx * a.bx;
+    __syncthreads();
+    // dY rows of this class: output voxel 2 i + p of low-resolution voxel i
+    for (int i = tid; i < TM * 8; i += 256) {
+      const int m = i >> 3, q = i & 7;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < nbox) {
+        const int x = m % a.bx, qq = m / a.bx, y = qq % a.by, z = qq / a.by;
+        const int iz = z0 + z, iy = y0 + y, ix = x0 + x;
+        const int co = cb * 32 + 4 * q;
+        if (iz < a.Zs && iy < a.Ys && ix < a.Xs && co < a.Co) {
+          const float *p = dy + ((((size_t)b * a.Zo + 2 * iz + pz) * a.Yo + 2 * iy + py) * a.Xo + 2 * ix + px) * dy_cs + co;
+          if (co + 3 < a.Co) v = *reinterpret_cast<const f32x4 *>(p);
+          else { v[0] = p[0]; v[1] = co + 1 < a.Co ? p[1] : 0.f; v[2] = co + 2 < a.Co ? p[2] : 0.f; }
+        }
+      }
+      *reinterpret_cast<f32x4 *>(&dyt[m * 32 + 4 * q]) = v;
+    }
+    // low-resolution input halo, origin i0 + p - 1 (zero outside the grid = the padding of the upsampled tensor)
+    for (int i = tid; i < HV * 8; i += 256) {
+      const int hv = i >> 3, q = i & 7;
+      const int hx = hv % HX, qq = hv / HX, hy = qq % HY, hz = qq / HY;
+      const int cz = z0 + hz + pz - 1, cy = y0 + hy + py - 1, cx = x0 + hx + px - 1;
+      const int c = ci0 + 4 * q;
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (c < Ctot && cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs) {
+        const size_t off = (((size_t)b * a.Zs + cz) * a.Ys + cy) * a.Xs + cx;
+        w = (c < a.C0) ? *reinterpret_cast<const f32x4 *>(a.src0 + off * a.C0 + c)
+                       : *reinterpret_cast<const f32x4 *>(a.src1 + off * a.C1 + (c - a.C0));
+      }
+      *reinterpret_cast<f32x4 *>(&at[hv * 32 + 4 * q]) = w;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int m0 = 2 * wave; m0 < TM; m0 += 8) {
+      const float av = dyt[(m0 + h) * 32 + r];
+      const int hb = rowhv[m0 + h] + r;
+      float bv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = at[hb + tapoff[e]];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[e], acc[e], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) lds[((wave - 1) * 16 + reg) * 64 + lane] = acc[e][reg];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      float *p = part + ((((size_t)blockIdx.x * gridDim.y + cb) * gridDim.z + kb) * 8 + e) * 1024;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        float v = acc[e][reg];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) v += lds[(w * 16 + reg) * 64 + lane];
+        p[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 32 + r] = v;
+      }
+    }
+  }
+}
+
+hipError_t launch_wgrad_par(const ConvArgs &a, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb, hipStream_t st) {
+  if (!a.par || a.gn || a.pm || a.ups || G < 1 || (a.C0 & 3) || (a.C1 & 3) || a.Zo != 2 * a.Zs || a.Yo != 2 * a.Ys || a.Xo != 2 * a.Xs)
+    return hipErrorInvalidValue;
+  const int nbox = a.bz * a.by * a.bx, TM = (nbox + 1) & ~1, HV = (a.bz + 1) * (a.by + 1) * (a.bx + 1);
+  if (TM > 256) return hipErrorInvalidValue;
+  const size_t lds = std::max<size_t>(((size_t)((TM + 3) & ~3) + (size_t)TM * 32 + (size_t)HV * 32) * 4, (size_t)3 * 1024 * 4);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(wgrad_par_kernel, dim3((unsigned)G * 8, (unsigned)ncb, (unsigned)nkb), dim3(256), lds, st, a, dy, dy_cs, part, G);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
 // 1x1x1 weight gradient over flat rows (see launch_wgrad_1x1).  grid (G, ncb, nkb / NKB).
 // --------------------------------------------------------------------------------
 template <int NKB>
