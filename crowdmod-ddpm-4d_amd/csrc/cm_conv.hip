@@ -63,7 +63,11 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
   // of 27 taps of MFMAs per block and half the halo box.  Bit-identical to the full form (the skipped products are
   // exact zeros).  427 = with the fused 1x1x1 skip convolution (as 127).
   constexpr bool ZS = SPEC && FAST >= 300;
-  static_assert(!ZS || (MB == 2 && BZ == 2 && BY * BX <= 32 && STR == 1 && (FAST % 100) == 27), "z-split: one plane per row block");
+  static_assert(!ZS || (MB == 2 && BZ == 2 && BY * BX <= 32 && STR == 1 && ((FAST % 100) == 27 || FAST == 308)), "z-split: one plane per row block");
+  // FAST 308: the same for the parity form of an upsample conv whose SOURCE has two planes (decoder_blocks.2): row block mb
+  // holds the source plane i = mb; class pz = 0 never issues (i = 0, e_z = 0), class pz = 1 never (i = 1, e_z = 1) -- 6 of 8
+  // (row block, z tap) pairs, and two staged planes instead of three
+  constexpr bool ZSP = ZS && (FAST % 100) == 8;
   constexpr bool SKIPC = FAST == 127 || FAST == 427;
   constexpr int STD = SPAR ? 2 : 3;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -399,7 +403,46 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
     if (ch == ch0) { CM_RT(2) }
     // ---- this wave's share of the (tap, 8-channel) steps ---------------------
     if (a.dbg & 2) continue;
-    if constexpr (ZS) {
+    if constexpr (ZSP) {
+      auto body = [&](auto PZ) {
+        constexpr int pzc = decltype(PZ)::value;
+        auto on = [](int t, int mb) { const int ez = t >> 2; return mb == 0 ? !(ez == 0 && pzc == 0) : !(ez == 1 && pzc == 1); };
+        auto off = [&](int t, int mb) { const int ez = t >> 2, ey = (t >> 1) & 1, ex = t & 1; return (((mb + ez + pzc - 1) * cHYs + ey) * cHXs + ex) * 36; };
+        const float *Aw = A + wave * 8;
+        f32x4 afn[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) afn[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          if (on(0, mb)) afn[mb] = *reinterpret_cast<const f32x4 *>(&Aw[abase[mb] + off(0, mb)]);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int d = t % PD;
+          f32x4 af[MB];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) af[mb] = afn[mb];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+            if (t + 1 < 8 && on(t + 1, mb)) afn[mb] = *reinterpret_cast<const f32x4 *>(&Aw[abase[mb] + off(t + 1, mb)]);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+              if (on(t, mb)) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                  acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mb][jj], bq[d][nb][jj], acc[mb][nb], 0, 0, 0);
+              }
+          if (wleft > 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bq[d][nb] = wrun[nb * 64];
+            wrun += 4 * NB * 64;
+            --wleft;
+          }
+        }
+      };
+      if (pz == 0) body(std::integral_constant<int, 0>{}); else body(std::integral_constant<int, 1>{});
+    } else if constexpr (ZS) {
       // all 27 taps unrolled: LDS offsets are immediates, and a row block skips the z tap that reads its padding plane
       auto zs_on = [](int t, int mb) { const int dz = t / 9; return mb == 0 ? dz >= 1 : dz <= 1; };
       auto zs_off = [&](int t, int mb) { const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3; return (((mb + dz - 1) * cHYs + dy) * cHXs + dx) * 36; };
@@ -863,6 +906,9 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
 #define CM_SPEC_PAR(m, n, z, y, x)                                                 \
   if (specpar && MB == m && NB == n && a.bz == z && a.by == y && a.bx == x) {      \
     if (a.f16) CM_LAUNCH_T((conv_mfma_kernel<m, n, 208, z, y, x>), m, n, 208)      \
+    if constexpr (m == 2 && n == 2 && z == 2 && y * x <= 32) {                     \
+      if (a.Zs == 2 && a.ntz == 1 && !(dbg & 16384)) CM_LAUNCH_T((conv_mfma_kernel<2, 2, 308, 2, y, x>), 2, 2, 308) \
+    }                                                                              \
     CM_LAUNCH_T((conv_mfma_kernel<m, n, 8, z, y, x>), m, n, 8)                     \
   }
 #define CM_SPEC_S2(m, n, z, y, x)                                                  \
