@@ -885,7 +885,7 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
   }
   CM_SPEC_ZS(3, 9)   // ATC 3 x 9 x 2
   CM_SPEC_ZS(6, 5)   // 2x grid 6 x 18 x 2
-  CM_SPEC_ZS(7, 4)   // HERMES-CR-120 7 x 6 x 2
+  // (HERMES-CR-120's 7 x 6 x 2 quarter resolution keeps its tuned MB3 2x7x6 tile: 84 of 96 rows; a 7 x 4 z-split tile was not tuned)
 #undef CM_SPEC_ZS
   CM_SPEC3(3, 1, 8, 6, 2)  // full resolution, three workgroups per CU (128 VGPRs): -7 % vs MB4 8x4x4 at 2 per CU
   CM_SPEC3(3, 1, 8, 4, 3)  //   (8x3x4, 4x4x6, 4x6x4, 8x2x6 measured slower: 118 / 136 / 111 / 134 us vs 108 on the 32->32 layer)
