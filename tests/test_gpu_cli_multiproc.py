@@ -170,3 +170,45 @@ def test_two_data_parallel_replicas_stay_identical(tmp_path):
     assert np.array_equal(a["hist"], b["hist"]) and float(a["lr"]) == float(b["lr"]) and len(a["hist"]) == 3
     assert np.array_equal(a["w"], b["w"]) and np.array_equal(a["b"], b["b"])
     assert np.isfinite(a["hist"]).all() and a["hist"][-1] < a["hist"][0]
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _lanes_worker(lanes, out_path):
+    if lanes > 1:
+        os.environ["CM_LANES"] = str(lanes)     # read once by the library, hence one process per setting
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from crowdmod_ddpm_4d_amd import prng, spec
+    from crowdmod_ddpm_4d_amd.config import AttrDict
+    from crowdmod_ddpm_4d_amd.ddpm_model import DDPM_model
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    gb = 19                                      # uneven lanes: 10 + 9 chains
+    H, W = FULL_GRIDS["atc"]
+    cfg = AttrDict({
+        "MACROPROPS": {"ROWS": H, "COLS": W}, "DATASET": {"PAST_LEN": 5, "FUTURE_LEN": 3, "BATCH_SIZE": gb},
+        "MODEL": {"NSAMPLES": gb, "NSAMPLES4PLOTS": 2, "DDPM": {
+            "SAMPLER": "DDPM", "TIMESTEPS": 5, "SCALE": 0.5, "SIGMA": 0.001, "DDIM_DIVIDER": 2, "GUIDANCE": "None",
+            "LAMBDA_GUIDANCE": 0.0,
+            "UNET": {"CONDITION": "Past", "NUM_RES_BLOCKS": 1, "BASE_CH": 32, "BASE_CH_MULT": [1, 2, 4],
+                     "APPLY_ATTENTION": [False, False, True, False], "DROPOUT_RATE": 0.1, "TIME_EMB_MULT": 4}}}})
+    model = DDPM_model(cfg, "DDPM-UNet", 4, device=0, seed=321)
+    model.denoiser.load_state_dict(spec.init_params(full_cfg(4), SEED_W))
+    sampler = DDPM(timesteps=5, scale=0.5, device=0)
+    past = prng.normal_per_sample(9, "lanes/past", np.arange(gb), 4 * H * W * 5).reshape(gb, 4, H, W, 5)
+    model._sample_calls = 0
+    np.save(out_path, model._generate_ddpm(past, sampler, gb, sample_id_base=0)[0])
+
+
+def test_two_stream_lanes_equal_the_single_lane_loop(tmp_path):
+    """`bench.py --lanes 2` / CM_LANES=2: the batch split into two lanes on two HIP streams inside one process gives the
+    chains of the single-lane loop bit for bit (batch-shard identity; the lanes share no buffer region)."""
+    ctx = mp.get_context("spawn")
+    outs = []
+    for lanes in (1, 2):
+        out = str(tmp_path / f"lanes{lanes}.npy")
+        p = ctx.Process(target=_lanes_worker, args=(lanes, out))
+        p.start()
+        p.join(timeout=600)
+        assert p.exitcode == 0
+        outs.append(np.load(out))
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
