@@ -785,10 +785,11 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   // more parallelism AND less weight traffic per workgroup is to split K over workgroups;
   // a second pass sums the partials in a fixed order and applies the epilogue.
   const int nchunks = a.nch0 + a.nch1;
-  if (s.ntaps == 27 && !parity && a.CK == 32 && nchunks >= 2 && s.out->V() <= 64 && s.Co <= 256 && s.Co == s.out->C &&
+  static const int qr_vmax = getenv("CM_QR_VMAX") ? atoi(getenv("CM_QR_VMAX")) : 96;   // HERMES-CR-120 quarter resolution: 84 voxels
+  if (s.ntaps == 27 && !parity && a.CK == 32 && nchunks >= 2 && s.out->V() <= qr_vmax && s.Co <= 256 && s.Co == s.out->C &&
       op.stat_act && !getenv("CM_NO_KSPLIT")) {
     static const int qr_ks = getenv("CM_QR_KS") ? atoi(getenv("CM_QR_KS")) : 4;
-    op.ks = std::max(1, std::min(nchunks, qr_ks));
+    op.ks = std::max(1, std::min(nchunks, s.out->V() > 64 ? std::min(qr_ks, 2) : qr_ks));   // (84 voxels: ks 2 3.06 ms, ks 4 3.12, none 3.16 per CR-120 step)
     const size_t need = (size_t)op.ks * m->cfg.max_batch * s.out->V() * s.Co;
     m->ks_scratch_floats = std::max(m->ks_scratch_floats, need);
     std::vector<float> zb((size_t)co_pad, 0.f);
