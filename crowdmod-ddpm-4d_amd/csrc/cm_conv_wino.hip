@@ -33,6 +33,19 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
+// a - b on four floats as two v_pk_add_f32 with negated second operand: the compiler scalarises a vector fsub into
+// four v_sub_f32 (there is no packed subtract), and three quarters of the Winograd transforms are subtractions
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_sub2(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
+  const f32x2 lo = pk_sub2(a.xy, b.xy), hi = pk_sub2(a.zw, b.zw);
+  return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+
 // Epilogue of one 32-voxel x 32-channel output sub-block (same arithmetic as the direct kernel's): bias, time-embedding
 // row, residual, channels-last store, GroupNorm statistics of the block in the slot format of gn_finalize.
 __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const f32x16 &v, const int *outoff, int nt, int wave, int lane,
@@ -279,10 +292,21 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
     };
     if constexpr (TWO) {
       // step A: this chunk's halo voxels (loaded during the previous matrix phase) -> activated image R
+      if (a.gn && a.silu && !a.pm) {            // (workgroup-uniform: the plain ResnetBlock conv; no selects on the flags)
 #pragma unroll
-      for (int k = 0; k < RK; ++k) {
-        const int v = (tid >> 2) + (NT / 4) * k;
-        if (v < RV) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = activate(ald[k], (aok >> k) & 1u);
+        for (int k = 0; k < RK; ++k) {
+          const int v = (tid >> 2) + (NT / 4) * k;
+          f32x4 w = ald[k] * sc1 + sh1;
+          w[0] = silu_w(w[0]); w[1] = silu_w(w[1]); w[2] = silu_w(w[2]); w[3] = silu_w(w[3]);
+          if (!((aok >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (v < RV) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = w;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {
+          const int v = (tid >> 2) + (NT / 4) * k;
+          if (v < RV) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = activate(ald[k], (aok >> k) & 1u);
+        }
       }
       __syncthreads();                        // R complete; every wave is past the previous chunk's matrix phase
 #pragma unroll
@@ -303,7 +327,7 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const f32x4 e0 = d[i * 4 + 0], e1 = d[i * 4 + 1], e2 = d[i * 4 + 2], e3 = d[i * 4 + 3];
-      d[i * 4 + 0] = e0 - e2; d[i * 4 + 1] = e1 + e2; d[i * 4 + 2] = e2 - e1; d[i * 4 + 3] = e1 - e3;
+      d[i * 4 + 0] = pk_sub(e0, e2); d[i * 4 + 1] = e1 + e2; d[i * 4 + 2] = pk_sub(e2, e1); d[i * 4 + 3] = pk_sub(e1, e3);
     }
     if constexpr (HALF) {
       // lane hf = 0 holds the x-transformed patch rows 0, 1; hf = 1 rows 2, 3.  y components: V0 = t0 - t2, V1 = t1 + t2
@@ -322,7 +346,7 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f32x4 e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j], e3 = d[3 * 4 + j];
-        d[0 * 4 + j] = e0 - e2; d[1 * 4 + j] = e1 + e2; d[2 * 4 + j] = e2 - e1; d[3 * 4 + j] = e1 - e3;
+        d[0 * 4 + j] = pk_sub(e0, e2); d[1 * 4 + j] = e1 + e2; d[2 * 4 + j] = pk_sub(e2, e1); d[3 * 4 + j] = pk_sub(e1, e3);
       }
     }
     if constexpr (!TWO) __syncthreads();    // previous chunk's fragments have been read
@@ -603,12 +627,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const ConvArgs a, co
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const f32x4 e0 = d[i * 4 + 0], e1 = d[i * 4 + 1], e2 = d[i * 4 + 2], e3 = d[i * 4 + 3];
-        d[i * 4 + 0] = e0 - e2; d[i * 4 + 1] = e1 + e2; d[i * 4 + 2] = e2 - e1; d[i * 4 + 3] = e1 - e3;
+        d[i * 4 + 0] = pk_sub(e0, e2); d[i * 4 + 1] = e1 + e2; d[i * 4 + 2] = pk_sub(e2, e1); d[i * 4 + 3] = pk_sub(e1, e3);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f32x4 e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j], e3 = d[3 * 4 + j];
-        d[0 * 4 + j] = e0 - e2; d[1 * 4 + j] = e1 + e2; d[2 * 4 + j] = e2 - e1; d[3 * 4 + j] = e1 - e3;
+        d[0 * 4 + j] = pk_sub(e0, e2); d[1 * 4 + j] = e1 + e2; d[2 * 4 + j] = pk_sub(e2, e1); d[3 * 4 + j] = pk_sub(e1, e3);
       }
       if (stager) {
         float *vw = V + (size_t)(zi * NP + patch) * 32 + 4 * quad;
