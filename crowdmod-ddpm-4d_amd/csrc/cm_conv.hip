@@ -797,6 +797,15 @@ bool conv_par_f16_variant(int MB, int NB, int bz, int by, int bx) {
          (MB == 3 && NB == 1 && bz == 2 && by == 7 && bx == 6) || (MB == 2 && NB == 2 && bz == 4 && by == 4 && bx == 4);
 }
 
+// does launch_conv run this (stride-1, one sample per tile) op in a z-split form?  (executed-FLOP accounting: 18 of 27
+// taps resp. 6 of 8 parity taps are issued)
+bool conv_zsplit_variant(const ConvArgs &a, int MB, int NB) {
+  if (conv_dbg_flags() & (2048 | 16384)) return false;
+  if (!(MB == 2 && NB == 2 && a.bz == 2 && a.ntz == 1 && a.bs == 1 && a.stride == 1 && !a.ups && a.CK == 32 && a.Zs == 2)) return false;
+  if (a.par) return a.ntaps == 8 && a.td == 2 && !a.f16 && a.by == 3 && a.bx == 9;
+  return a.ntaps == 27 && a.td == 3 && a.Zo == 2 && ((a.by == 3 && a.bx == 9) || (a.by == 6 && a.bx == 5));
+}
+
 bool conv_variant_exists(int MB, int NB) {
 #define X(m, n) if (MB == m && NB == n) return true;
   CM_CONV_VARIANTS(X)

@@ -70,6 +70,7 @@ struct ConvArgs {
   int zsplit;          // weight gradient of a 27-tap layer on a two-plane grid: mtab rows [0,32) are plane 0, [32,64) plane 1,
                        //   and a row block skips the z tap that multiplies its padding plane (18 of 27 taps, as the forward)
 };
+bool conv_zsplit_variant(const ConvArgs &a, int MB, int NB);
 // does launch_conv have an f16-operand instantiation for this parity-form tile?
 bool conv_par_f16_variant(int MB, int NB, int bz, int by, int bx);
 

@@ -2109,6 +2109,9 @@ int cm_model_exec_flops(const cm_model *m, int32_t B, double flops[8]) {
       }
     } else if (a.par) {
       f = op.flops_per_sample * 8.0 / 27.0;
+      if (cm::conv_zsplit_variant(a, op.MB, op.NB)) f *= 6.0 / 8.0;    // two-plane source: 6 of 8 (row block, z tap) pairs
+    } else if (cm::conv_zsplit_variant(a, op.MB, op.NB)) {
+      f *= 18.0 / 27.0;                                                // two-plane grid: the padding-plane tap is never issued
     }
     flops[op.cls] += f * B;
   }
