@@ -544,16 +544,18 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
 // over all tiles of the workgroup; partials part[g][cb][kb][dz][xi][ci][co], summed and transformed by
 // wgrad_wino_reduce_kernel in a fixed order.  One workgroup per CU (V image 80 KB + 192 accumulator registers).
 template <int BZ, int PY, int PX>
-__global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const ConvArgs a, const float *__restrict__ dy, int dy_cs,
+__global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const ConvArgs a, const float *__restrict__ dy, int dy_cs,
                                                             float *__restrict__ part, int G) {
   constexpr int NP = PY * PX, ROWS = BZ * NP, HZ = BZ + 2, UR = HZ * NP;
   static_assert(ROWS <= 32 && ROWS > 16, "one (partly filled) 32-row block");
-  constexpr int NIT = HZ * NP * 8, NRND = (NIT + 255) / 256;     // staging items (plane, patch, channel quad of 32 ci)
+  constexpr int NIT = HZ * NP * 8;               // staging items (plane, patch, channel quad of 32 ci): one per thread
+  static_assert(NIT <= 512, "one staging round of the 512 threads");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *V = lds;                                  // [16][UR][32]
   float *Yt = V + 16 * UR * 32;                    // [32 rows][32 co][4 = (a, b)]
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = w8 & 3, xh = w8 >> 2;          // frequency row xi_y, and which two of its four xi_x components
   const int r = lane & 31, hh = lane >> 5;
   const int g = blockIdx.x, cb = blockIdx.y, kb = blockIdx.z;
   const int Ctot = a.C0 + a.C1;
@@ -563,11 +565,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const ConvArgs a, co
   // A^T rows (1,1,1,0), (0,1,-1,-1)  =>  A = (1,0), (1,1), (1,-1), (0,-1): this wave's row of A along y
   const float cy0 = wave == 3 ? 0.f : 1.f, cy1 = wave == 0 ? 0.f : (wave == 1 ? 1.f : -1.f);
 
-  f32x16 acc[3][4];
+  f32x16 acc[3][2];
 #pragma unroll
   for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[dz][x][i] = 0.f;
 
@@ -581,9 +583,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const ConvArgs a, co
     const int z0 = tz * BZ, y0 = 2 * py0, x0 = 2 * px0;
     __syncthreads();                               // previous tile's operands have been read
     // ---- V = B^T d B of the conv's actual input (GroupNorm + SiLU + Dropout3d multiplier as in the forward) ----
-#pragma unroll 1
-    for (int rnd = 0; rnd < NRND; ++rnd) {
-      const int it = tid + 256 * rnd;
+    {
+      const int it = tid;
       const bool stager = it < NIT;
       const int itc = stager ? it : 0;
       const int quad = itc & 7, patch = (itc >> 3) % NP, zi = itc / (8 * NP);
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const ConvArgs a, co
       }
     }
     // ---- raw dY patches of the 32 rows: Yt[row][co][(a, b)]; rows this tile does not own contribute nothing ----
-    {
+    if (tid < 256) {
       const int row = tid >> 3, q = tid & 7;
       const int zr = row / NP, pr = row % NP, py = pr / PX, px = pr % PX;
       const bool own = row < ROWS && py0 + py >= ty * PY && px0 + px >= tx * PX;
@@ -667,15 +668,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const ConvArgs a, co
       const int row = 2 * p + hh;
       const f32x4 yv = *reinterpret_cast<const f32x4 *>(Yt + ((size_t)row * 32 + r) * 4);
       const float t0 = cy0 * yv[0] + cy1 * yv[2], t1 = cy0 * yv[1] + cy1 * yv[3];      // A along y: rows a = 0, 1
-      const float bm[4] = {t0, t0 + t1, t0 - t1, -t1};                                  // A along x
+      const float bm0 = xh ? t0 - t1 : t0, bm1 = xh ? -t1 : t0 + t1;                     // A along x: components 2 xh, 2 xh + 1
       const int vrow = min(row, ROWS - 1);
 #pragma unroll
       for (int dz = 0; dz < 3; ++dz) {
-        float av[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) av[x] = vb[((size_t)x * UR + vrow + dz * NP) * 32];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) acc[dz][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bm[x], acc[dz][x], 0, 0, 0);
+        const float av0 = vb[((size_t)(2 * xh) * UR + vrow + dz * NP) * 32], av1 = vb[((size_t)(2 * xh + 1) * UR + vrow + dz * NP) * 32];
+        acc[dz][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bm0, acc[dz][0], 0, 0, 0);
+        acc[dz][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bm1, acc[dz][1], 0, 0, 0);
       }
     }
   }
@@ -683,8 +682,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const ConvArgs a, co
 #pragma unroll
   for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      float *p = part + (((((size_t)g * gridDim.y + cb) * gridDim.z + kb) * 3 + dz) * 16 + wave * 4 + x) * 1024;
+    for (int x = 0; x < 2; ++x) {
+      float *p = part + (((((size_t)g * gridDim.y + cb) * gridDim.z + kb) * 3 + dz) * 16 + wave * 4 + 2 * xh + x) * 1024;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
@@ -754,7 +753,7 @@ hipError_t launch_wgrad_wino(const ConvArgs &a, const float *dy, int dy_cs, floa
       if (e != hipSuccess) return e;                                                                        \
       attr_set[dev & 63] = true;                                                                            \
     }                                                                                                       \
-    hipLaunchKernelGGL((wgrad_wino_kernel<z, py, px>), dim3(G, ncb, nkb), dim3(256), lds, st, a, dy, dy_cs, part, G); \
+    hipLaunchKernelGGL((wgrad_wino_kernel<z, py, px>), dim3(G, ncb, nkb), dim3(512), lds, st, a, dy, dy_cs, part, G); \
     return hipGetLastError();                                                                               \
   }
   CM_WINO_TILES(X)
