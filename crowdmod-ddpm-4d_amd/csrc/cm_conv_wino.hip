@@ -695,24 +695,40 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const ConvArgs a, co
 // dW[co][ci][kH][kW][kL] (reference layout) = sum_g G^T dU G of the partials (fixed order)
 __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float *__restrict__ part, int G, int ncb, int nkb, int Co, int Ci,
                                                                 float *__restrict__ dW) {
+  // 32 outputs (consecutive co) x 8 group lanes per workgroup: lane l sums the groups l, l + 8, ... of all 16 components,
+  // the lanes are merged in lane order through LDS (a fixed summation order), lane 0 transforms and stores
+  __shared__ float sh[8][16][32];
   const long long n = (long long)ncb * nkb * 3 * 1024;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int col = (int)(i & 31), cil = (int)((i >> 5) & 31);
-  long long q = i >> 10;
+  const long long i = (long long)blockIdx.x * 32 + (threadIdx.x & 31);
+  const int gl = threadIdx.x >> 5;
+  const bool live = i < n;
+  const long long ic = live ? i : 0;
+  const int col = (int)(ic & 31), cil = (int)((ic >> 5) & 31);
+  long long q = ic >> 10;
   const int dz = (int)(q % 3); q /= 3;
   const int kb = (int)(q % nkb);
   const int cb = (int)(q / nkb);
   const int co = cb * 32 + col, ci = kb * 32 + cil;
-  if (co >= Co || ci >= Ci) return;
   const long long per_g = (long long)ncb * nkb * 3 * 16 * 1024;
   float u[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) u[k] = 0.f;
   const float *p = part + ((((size_t)cb * nkb + kb) * 3 + dz) * 16) * 1024 + cil * 32 + col;
-  for (int g = 0; g < G; ++g)
+  if (live)
+    for (int g = gl; g < G; g += 8)
 #pragma unroll
-    for (int k = 0; k < 16; ++k) u[k] += p[(size_t)g * per_g + (size_t)k * 1024];
+      for (int k = 0; k < 16; ++k) u[k] += p[(size_t)g * per_g + (size_t)k * 1024];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) sh[gl][k][threadIdx.x & 31] = u[k];
+  __syncthreads();
+  if (gl != 0 || !live || co >= Co || ci >= Ci) return;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float t = sh[0][k][threadIdx.x];
+#pragma unroll
+    for (int l = 1; l < 8; ++l) t += sh[l][k][threadIdx.x];
+    u[k] = t;
+  }
   // G^T u G with G = (1,0,0), (1/2,1/2,1/2), (1/2,-1/2,1/2), (0,0,1):  G^T rows = (1, 1/2, 1/2, 0), (0, 1/2, -1/2, 0), (0, 1/2, 1/2, 1)
   float s[4][3];
 #pragma unroll
@@ -763,7 +779,7 @@ hipError_t launch_wgrad_wino(const ConvArgs &a, const float *dy, int dy_cs, floa
 
 hipError_t launch_wgrad_wino_reduce(const float *part, int G, int ncb, int nkb, int Co, int Ci, float *dW, hipStream_t st) {
   const long long n = (long long)ncb * nkb * 3 * 1024;
-  hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, G, ncb, nkb, Co, Ci, dW);
+  hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, G, ncb, nkb, Co, Ci, dW);
   return hipGetLastError();
 }
 
