@@ -238,6 +238,12 @@ hipError_t launch_wgrad_1x1(const ConvArgs &a, const float *dy, int dy_cs, long 
 // Tile box (a.bz, a.by, a.bx) in low-resolution voxels, a.ntz/nty/ntx tiles per sample; a.gn / a.pm must be null.
 hipError_t launch_wgrad_par(const ConvArgs &a, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb, hipStream_t st);
 
+// Deferred per-sample voxel sums of the backward pass (bias gradient and the broadcast time-embedding term of every
+// conv): out[b][c] = sum_v x[b][v][c], optionally mirrored into out2 (the time-projection gradient row).  One launch for
+// the whole job table; grid (B * ncb_max, njobs).
+struct VsumJob { const float *x; int V, C, cs; float *out; int ostride; float *out2; int ostride2; };
+hipError_t launch_voxel_sum_jobs(const VsumJob *jobs, int njobs, int B, int maxC, hipStream_t st);
+
 // Deferred per-parameter batch reductions of the backward pass (bias, GroupNorm gamma / beta gradients): one launch
 // for the whole job table instead of one ~5 us launch each.  out[c] = sum_b in[b * stride + c], fixed order.
 struct BsumJob { const float *in; float *out; int C, stride; };

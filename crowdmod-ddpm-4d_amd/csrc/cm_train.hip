@@ -754,6 +754,39 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float *__restrict_
   }
 }
 
+__global__ __launch_bounds__(256) void voxel_sum_jobs_kernel(const VsumJob *__restrict__ jobs, int ncb_max) {
+  __shared__ float sh[256];
+  const VsumJob j = jobs[blockIdx.y];
+  const int b = blockIdx.x / ncb_max, cbk = blockIdx.x - b * ncb_max;
+  if (cbk * 32 >= j.C) return;                 // (workgroup-uniform)
+  const int tid = threadIdx.x;
+  const int c = cbk * 32 + (tid & 31), vl = tid >> 5;   // 8 voxel lanes, four running sums each (fixed order)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < j.C) {
+    const float *p = j.x + (size_t)b * j.V * j.cs + c;
+    int v = vl;
+    for (; v + 24 < j.V; v += 32) {
+      s0 += p[(size_t)v * j.cs]; s1 += p[(size_t)(v + 8) * j.cs]; s2 += p[(size_t)(v + 16) * j.cs]; s3 += p[(size_t)(v + 24) * j.cs];
+    }
+    for (; v < j.V; v += 8) s0 += p[(size_t)v * j.cs];
+  }
+  sh[tid] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (tid < 32 && c < j.C) {
+    float t = 0.f;
+    for (int l = 0; l < 8; ++l) t += sh[l * 32 + tid];
+    j.out[(size_t)b * j.ostride + c] = t;
+    if (j.out2) j.out2[(size_t)b * j.ostride2 + c] = t;
+  }
+}
+
+hipError_t launch_voxel_sum_jobs(const VsumJob *jobs, int njobs, int B, int maxC, hipStream_t st) {
+  if (njobs <= 0) return hipSuccess;
+  const int ncb = (maxC + 31) / 32;
+  hipLaunchKernelGGL(voxel_sum_jobs_kernel, dim3((unsigned)(B * ncb), (unsigned)njobs), dim3(256), 0, st, jobs, ncb);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void batch_sum_jobs_kernel(const BsumJob *__restrict__ jobs, int B) {
   __shared__ float sh[256];
   const BsumJob j = jobs[blockIdx.y];
