@@ -294,7 +294,9 @@ hipError_t launch_sumpool2(const float *y, float *x, int B, int Z, int Y, int X,
 hipError_t launch_zero_stuff2(const float *y, float *u, int B, int Z, int Y, int X, int C, hipStream_t st);
 hipError_t launch_mse_grad(const float *pred, const float *target, float *g, int B, int C, int H, int W, int P, int F,
                            hipStream_t st);
-hipError_t launch_attn_bwd(const float *qkv, const float *dO, float *dqkv, int B, int S, int E, int heads, hipStream_t st);
+// `big`: global scratch of attn_bwd_scratch_floats() floats when the S x S matrices exceed LDS (0 floats = not needed)
+size_t attn_bwd_scratch_floats(int B, int S, int E, int heads);
+hipError_t launch_attn_bwd(const float *qkv, const float *dO, float *dqkv, int B, int S, int E, int heads, float *big, hipStream_t st);
 struct TimeBwdArgs {
   const float *table; const long long *t;
   const float *W1, *b1, *W2, *b2, *Wd, *bd;

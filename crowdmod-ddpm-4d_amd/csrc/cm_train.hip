@@ -1060,12 +1060,15 @@ hipError_t launch_mse_grad(const float *pred, const float *target, float *g, int
 // --------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ dO,
-                                                       float *__restrict__ dqkv, int S, int E) {
+                                                       float *__restrict__ dqkv, int S, int E, float *__restrict__ big) {
   // Q K V dO [S][D + 1] (odd row stride: a lane per key row reads conflict-free), P [S][S], dS [S][S]
+  // `big` != null (S x S matrices too large for LDS, e.g. 216 tokens on the doubled grid): P and dS of this
+  // (sample, head) live in a global scratch slab instead; same code, slower, exact same arithmetic
   constexpr int DP = D + 1;
   extern __shared__ float sm[];
-  float *Q = sm, *K = Q + S * DP, *Vv = K + S * DP, *dOs = Vv + S * DP, *Pm = dOs + S * DP, *dSm = Pm + S * S;
   const int hd = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  float *Q = sm, *K = Q + S * DP, *Vv = K + S * DP, *dOs = Vv + S * DP;
+  float *Pm = big ? big + ((size_t)b * gridDim.x + hd) * 2 * S * S : dOs + S * DP, *dSm = Pm + S * S;
   const float *base = qkv + (size_t)b * S * 3 * E;
   for (int i = tid; i < S * D; i += 256) {
     const int s = i / D, d = i % D;
@@ -1088,6 +1091,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__
     Pm[idx] = sc * scale;
     dSm[idx] = dp;
   }
+  if (big) __threadfence_block();               // (global scratch written by other threads of this workgroup)
   __syncthreads();
   // row softmax and dS = P o (dP - rowsum(dP o P)): four adjacent lanes per row, merged by shuffles in a fixed order
   for (int r0 = 0; r0 < S; r0 += 64) {
@@ -1108,6 +1112,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__
     dot += __shfl_xor(dot, 2);
     if (ok) for (int j = l4; j < S; j += 4) dSm[row * S + j] = Pm[row * S + j] * (dSm[row * S + j] - dot);
   }
+  if (big) __threadfence_block();
   __syncthreads();
   float *ob = dqkv + (size_t)b * S * 3 * E;
   for (int i = tid; i < S * D; i += 256) {
@@ -1124,16 +1129,28 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__
   }
 }
 
-hipError_t launch_attn_bwd(const float *qkv, const float *dO, float *dqkv, int B, int S, int E, int heads, hipStream_t st) {
+size_t attn_bwd_scratch_floats(int B, int S, int E, int heads) {
   const int D = E / heads;
   const size_t smem = ((size_t)4 * S * (D + 1) + (size_t)2 * S * S) * sizeof(float);
-  if (smem > 160 * 1024) return hipErrorInvalidValue;
+  return smem > 160 * 1024 ? (size_t)B * heads * 2 * S * S : 0;
+}
+
+hipError_t launch_attn_bwd(const float *qkv, const float *dO, float *dqkv, int B, int S, int E, int heads, float *big, hipStream_t st) {
+  const int D = E / heads;
+  size_t smem = ((size_t)4 * S * (D + 1) + (size_t)2 * S * S) * sizeof(float);
+  if (smem > 160 * 1024) {
+    if (!big) return hipErrorInvalidValue;
+    smem = (size_t)4 * S * (D + 1) * sizeof(float);
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+  } else {
+    big = nullptr;
+  }
 #define CM_AB(DD)                                                                                         \
   if (D == DD) {                                                                                          \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_kernel<DD>),               \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
     if (e != hipSuccess) return e;                                                                        \
-    hipLaunchKernelGGL((attn_bwd_kernel<DD>), dim3(heads, B), dim3(256), smem, st, qkv, dO, dqkv, S, E);    \
+    hipLaunchKernelGGL((attn_bwd_kernel<DD>), dim3(heads, B), dim3(256), smem, st, qkv, dO, dqkv, S, E, big);    \
     return hipGetLastError();                                                                             \
   }
   CM_AB(8) CM_AB(16) CM_AB(32) CM_AB(64)
