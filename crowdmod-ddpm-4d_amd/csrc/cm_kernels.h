@@ -244,6 +244,11 @@ hipError_t launch_wgrad_par(const ConvArgs &a, const float *dy, int dy_cs, float
 struct VsumJob { const float *x; int V, C, cs; float *out; int ostride; float *out2; int ostride2; };
 hipError_t launch_voxel_sum_jobs(const VsumJob *jobs, int njobs, int B, int maxC, hipStream_t st);
 
+// dst[i] = src[i] for a table of contiguous segments in ONE launch (the per-block slices of the time-projection
+// gradients go to their parameters' slots: 22 device-to-device copies per step otherwise)
+struct CopyJob { float *dst; const float *src; long long n; };
+hipError_t launch_copy_jobs(const CopyJob *jobs, int njobs, long long max_n, hipStream_t st);
+
 // Deferred per-parameter batch reductions of the backward pass (bias, GroupNorm gamma / beta gradients): one launch
 // for the whole job table instead of one ~5 us launch each.  out[c] = sum_b in[b * stride + c], fixed order.
 struct BsumJob { const float *in; float *out; int C, stride; };

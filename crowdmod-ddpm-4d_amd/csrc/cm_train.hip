@@ -754,6 +754,18 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float *__restrict_
   }
 }
 
+__global__ __launch_bounds__(256) void copy_jobs_kernel(const CopyJob *__restrict__ jobs) {
+  const CopyJob j = jobs[blockIdx.y];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < j.n; i += (long long)gridDim.x * 256) j.dst[i] = j.src[i];
+}
+
+hipError_t launch_copy_jobs(const CopyJob *jobs, int njobs, long long max_n, hipStream_t st) {
+  if (njobs <= 0) return hipSuccess;
+  const unsigned gx = (unsigned)std::min<long long>(64, (max_n + 255) / 256);
+  hipLaunchKernelGGL(copy_jobs_kernel, dim3(gx, (unsigned)njobs), dim3(256), 0, st, jobs);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void voxel_sum_jobs_kernel(const VsumJob *__restrict__ jobs, int ncb_max) {
   __shared__ float sh[256];
   const VsumJob j = jobs[blockIdx.y];
@@ -1202,14 +1214,19 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const float *__restrict
   const long long m = i / N;
   const float *ap = A + m * sam;
   const float *bp = Bm + n;
-  float acc0 = 0.f, acc1 = 0.f;
+  // eight loads of each operand in flight per round (the operands are L2-resident: one ~1 us round trip per round
+  // instead of one per k pair), eight running sums merged in a fixed order
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int k = 0;
-  for (; k + 1 < K; k += 2) {
-    acc0 = fmaf(ap[(long long)k * sak], bp[(long long)k * sbk], acc0);
-    acc1 = fmaf(ap[(long long)(k + 1) * sak], bp[(long long)(k + 1) * sbk], acc1);
+  for (; k + 7 < K; k += 8) {
+    float av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { av[u] = ap[(long long)(k + u) * sak]; bv[u] = bp[(long long)(k + u) * sbk]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = fmaf(av[u], bv[u], acc[u]);
   }
-  if (k < K) acc0 = fmaf(ap[(long long)k * sak], bp[(long long)k * sbk], acc0);
-  float v = acc0 + acc1;
+  for (; k < K; ++k) acc[0] = fmaf(ap[(long long)k * sak], bp[(long long)k * sbk], acc[0]);
+  float v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   if (pre) { const float y = pre[i], sg = sigmoid_f(y); v *= sg * (1.0f + y * (1.0f - sg)); }
   Cm[i] = v;
 }
