@@ -314,7 +314,8 @@ hipError_t launch_time_bwd(const TimeBwdArgs &a, hipStream_t st);
 hipError_t launch_adam(float *p, const float *g, float *m, float *v, long long n, float lr, float b1, float b2,
                        float eps, float wd, int step, hipStream_t st);
 hipError_t launch_gather_pack(const float *W, const int *idx, int nk, float *packed, long long n, hipStream_t st);
-struct PackJob { float *dst; const int *idx; const float *coef; long long start; int nk; int pad; };   // coef: optional weights of the nk terms
-hipError_t launch_gather_pack_jobs(const float *W, const PackJob *jobs, int njobs, long long total, hipStream_t st);
+struct PackJob { float *dst; const int *idx; const float *coef; long long start; int nk; int pad; long long n; long long blk0; };   // coef: optional weights of the nk terms; n elements from workgroup blk0 on
+// blk2job[workgroup] = job index (each job owns ceil(n / 256) consecutive workgroups: no per-element search)
+hipError_t launch_gather_pack_jobs(const float *W, const PackJob *jobs, const int *blk2job, long long nblocks, hipStream_t st);
 
 }  // namespace cm

@@ -1302,17 +1302,10 @@ __global__ void gather_pack_kernel(const float *__restrict__ W, const int *__res
 
 // All re-packs of one optimizer step in ONE launch: job j covers the global element range
 // [start[j], start[j+1]); a thread finds its job by bisection over the (few hundred) starts.
-__global__ void gather_pack_jobs_kernel(const float *__restrict__ W, const PackJob *__restrict__ jobs, int njobs,
-                                        long long total) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  int lo = 0, hi = njobs - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid].start <= i) lo = mid; else hi = mid - 1;
-  }
-  const PackJob jb = jobs[lo];
-  const long long e = i - jb.start;
+__global__ void gather_pack_jobs_kernel(const float *__restrict__ W, const PackJob *__restrict__ jobs, const int *__restrict__ blk2job) {
+  const PackJob jb = jobs[blk2job[blockIdx.x]];
+  const long long e = ((long long)blockIdx.x - jb.blk0) * 256 + threadIdx.x;
+  if (e >= jb.n) return;
   float s = 0.f;
   for (int k = 0; k < jb.nk; ++k) {
     const int j = jb.idx[e * jb.nk + k];
@@ -1321,8 +1314,9 @@ __global__ void gather_pack_jobs_kernel(const float *__restrict__ W, const PackJ
   jb.dst[e] = s;
 }
 
-hipError_t launch_gather_pack_jobs(const float *W, const PackJob *jobs, int njobs, long long total, hipStream_t st) {
-  hipLaunchKernelGGL(gather_pack_jobs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, jobs, njobs, total);
+hipError_t launch_gather_pack_jobs(const float *W, const PackJob *jobs, const int *blk2job, long long nblocks, hipStream_t st) {
+  if (nblocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_pack_jobs_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, W, jobs, blk2job);
   return hipGetLastError();
 }
 
