@@ -48,13 +48,14 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
 
 // Epilogue of one 32-voxel x 32-channel output sub-block (same arithmetic as the direct kernel's): bias, time-embedding
 // row, residual, channels-last store, GroupNorm statistics of the block in the slot format of gn_finalize.
+// `bias`, `tv`: bias and time-embedding row value of this lane's output channel, loaded in the kernel's PROLOGUE -- the
+// row sits behind two dependent loads (t index, table) that would otherwise be exposed at the very end of the workgroup.
 __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const f32x16 &v, const int *outoff, int nt, int wave, int lane,
-                                              int b0, int bs, int slot) {
+                                              int b0, int bs, int slot, float bias, float tv) {
   const int r = lane & 31, hh = lane >> 5;
   const int n = nt * 32 + r;
   const bool nok = n < a.Co;
   const int nc = nok ? n : 0;
-  const float bias = a.bias[nc];
   int offs[16];
   float rs[16];
 #pragma unroll
@@ -62,7 +63,6 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const f32x16 &v
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) rs[reg] = v[reg] + bias;
   if (a.temb) {
-    const float tv = a.temb[(size_t)a.tidx[bs] * a.temb_stride + nc];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) rs[reg] += tv;
   }
@@ -177,11 +177,15 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
   const int tz = tile % a.ntz;
   const int b0 = tile / a.ntz;
   const int nt = blockIdx.y * NBW + nbw;
+  // epilogue operands of this lane's output channel, requested now (see wino_epilogue)
+  const int nc_epi = nt * 32 + r < a.Co ? nt * 32 + r : 0;
+  const float bias_pre = a.bias[nc_epi];
   // patch origin of the tile (shifted back inside the grid if it would stick out) and the first patch it OWNS
   const int pyt = a.Yo >> 1, pxt = a.Xo >> 1;
   const int py0 = min(ty * PY, pyt - PY), px0 = min(tx * PX, pxt - PX);
   const int z0 = tz * BZ, y0 = 2 * py0, x0 = 2 * px0;
   const int bs = b0 < a.B ? b0 : 0;             // (grid is exact; kept for safety)
+  const float tv_pre = a.temb ? a.temb[(size_t)a.tidx[bs] * a.temb_stride + nc_epi] : 0.f;
 
   if (tid < 128) {
     const int ab = tid >> 5, row = tid & 31;
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
       wino_skip_mfma(n2, c0s, sa, sw, v);
     }
   }
-  wino_epilogue(a, v, outoff, nt, wave, lane, b0, bs, (((tz * a.nty + ty) * a.ntx) + tx) * 4 + wave);
+  wino_epilogue(a, v, outoff, nt, wave, lane, b0, bs, (((tz * a.nty + ty) * a.ntx) + tx) * 4 + wave, bias_pre, tv_pre);
 }
 
 // instantiated tiles (bz planes, by / 2 x bx / 2 patches): full resolution 8 x 2 x 2 (32 rows), half resolution of the
