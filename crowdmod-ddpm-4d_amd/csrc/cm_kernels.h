@@ -238,6 +238,13 @@ hipError_t launch_wgrad_1x1(const ConvArgs &a, const float *dy, int dy_cs, long 
 // Tile box (a.bz, a.by, a.bx) in low-resolution voxels, a.ntz/nty/ntx tiles per sample; a.gn / a.pm must be null.
 hipError_t launch_wgrad_par(const ConvArgs &a, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb, hipStream_t st);
 
+// Weight gradient of a 27-tap stride-1 conv on a grid with exactly two z planes (quarter resolution): dedicated form of
+// wgrad_kernel<true>.  512 threads; one workgroup = (tile group, 32 co, TWO 32-channel input blocks); the halo holds the
+// two real planes only (a row block never multiplies its padding plane), coordinates are arithmetic (no table loads in
+// the tile loop), every load of a tile is issued in one batch; wave w owns in-plane tap q = w of every z tap, wave dz the
+// ninth one (q = 8) of z tap dz.  Partials in wgrad_reduce's layout part[G][ncb][nkb][27][32 co][32 ci].
+hipError_t launch_wgrad_zs(const ConvArgs &a, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb, hipStream_t st);
+
 // Deferred per-sample voxel sums of the backward pass (bias gradient and the broadcast time-embedding term of every
 // conv): out[b][c] = sum_v x[b][v][c], optionally mirrored into out2 (the time-projection gradient row).  One launch for
 // the whole job table; grid (B * ncb_max, njobs).

@@ -232,6 +232,142 @@ hipError_t launch_wgrad(const ConvArgs &a, int MB, const float *dy, int dy_cs, f
 }
 
 // --------------------------------------------------------------------------------
+// Two-plane (quarter-resolution) weight gradient (see launch_wgrad_zs).  grid (G, ncb, ceil(nkb / 2)).
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void wgrad_zs_kernel(const ConvArgs a, const float *__restrict__ dy, int dy_cs,
+                                                          float *__restrict__ part, int G, int nkb) {
+  constexpr int NKB = 2, XS = 32 * NKB;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7: in-plane tap q = wave of every z tap
+  const int r = lane & 31, h = lane >> 5;
+  const int g = blockIdx.x, cb = blockIdx.y, kg = blockIdx.z;
+  const int HY = a.by + 2, HX = a.bx + 2, PL = HY * HX, HV = 2 * PL;
+  const int nrow = a.by * a.bx;               // valid rows per plane (<= 32)
+  int *rowhv = reinterpret_cast<int *>(lds);   // [64] in-plane halo offset (x XS) of a row's own voxel
+  float *dyt = lds + 64;                       // [64][32]: rows [0,32) plane 0, [32,64) plane 1
+  float *at = dyt + 64 * 32;                   // [2][HY][HX][XS]
+  if (tid < 64) {
+    const int rr = tid & 31;
+    const int y = rr < nrow ? rr / a.bx : 0, x = rr < nrow ? rr % a.bx : 0;
+    rowhv[tid] = (y * HX + x) * XS;
+  }
+  const int Ctot = a.C0 + a.C1;
+  const int qy = wave / 3, qx = wave - 3 * qy;               // in-plane tap (dy, dx) = (q / 3, q % 3) of q = wave
+  const int off_main = (qy * HX + qx) * XS, off_x = (2 * HX + 2) * XS;   // q = 8: (2, 2)
+  f32x16 acc[3][NKB], accx[NKB];               // [z tap][input block]; the extra tap (q = 8) of z tap dz = wave
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int k = 0; k < NKB; ++k)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[d][k][j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < NKB; ++k)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) accx[k][j] = 0.f;
+  const int ntile = a.B * a.nty * a.ntx;
+  for (int tile = g; tile < ntile; tile += G) {
+    int tt = tile;
+    const int tx = tt % a.ntx; tt /= a.ntx;
+    const int ty = tt % a.nty;
+    const int b = tt / a.nty;
+    const int y0 = ty * a.by, x0 = tx * a.bx;
+    __syncthreads();
+    // dY rows (plane z in row block z)
+    {
+      const int m = tid >> 3, q = tid & 7;       // 64 rows x 8 channel quads = 512 items
+      const int z = m >> 5, rr = m & 31;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (rr < nrow) {
+        const int oy = y0 + rr / a.bx, ox = x0 + rr % a.bx, co = cb * 32 + 4 * q;
+        if (oy < a.Yo && ox < a.Xo && co < a.Co) {
+          const float *p = dy + ((((size_t)b * 2 + z) * a.Yo + oy) * a.Xo + ox) * dy_cs + co;
+          if (co + 3 < a.Co) v = *reinterpret_cast<const f32x4 *>(p);
+          else { v[0] = p[0]; v[1] = co + 1 < a.Co ? p[1] : 0.f; v[2] = co + 2 < a.Co ? p[2] : 0.f; }
+        }
+      }
+      *reinterpret_cast<f32x4 *>(&dyt[m * 32 + 4 * q]) = v;
+    }
+    // the two real planes of the conv's input with their in-plane halo (activation recomputed as the forward stages it)
+    for (int i = tid; i < HV * 8 * NKB; i += 512) {
+      const int hv = i / (8 * NKB), q = i - hv * (8 * NKB);
+      const int hz = hv / PL, rem = hv - hz * PL, hy = rem / HX, hx = rem - hy * HX;
+      const int cy = y0 + hy - 1, cx = x0 + hx - 1;
+      const int c = kg * XS + 4 * q;
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (c < Ctot && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs) {
+        const size_t off = (((size_t)b * 2 + hz) * a.Ys + cy) * a.Xs + cx;
+        w = (c < a.C0) ? *reinterpret_cast<const f32x4 *>(a.src0 + off * a.C0 + c)
+                       : *reinterpret_cast<const f32x4 *>(a.src1 + off * a.C1 + (c - a.C0));
+        if (a.gn) {
+          const float *gp = a.gn + (size_t)b * 2 * Ctot + c;
+          w = w * *reinterpret_cast<const f32x4 *>(gp) + *reinterpret_cast<const f32x4 *>(gp + Ctot);
+          if (a.silu) { w[0] *= sigmoid_f(w[0]); w[1] *= sigmoid_f(w[1]); w[2] *= sigmoid_f(w[2]); w[3] *= sigmoid_f(w[3]); }
+        }
+        if (a.pm) w = w * *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + c);
+      }
+      *reinterpret_cast<f32x4 *>(&at[hv * XS + 4 * q]) = w;
+    }
+    __syncthreads();
+    // plane z uses the z taps dz = 1 - z, 2 - z ... i.e. z = 0: dz in {1, 2} (source planes 0, 1), z = 1: dz in {0, 1}
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+      const int dzs = 1 - z;                     // first of the two z taps of this plane; its source plane is 0, the next one 1
+      const bool x0w = wave == dzs, x1w = wave == dzs + 1;
+#pragma unroll 2
+      for (int m0 = 32 * z; m0 < 32 * z + 32; m0 += 2) {
+        const float av = dyt[(m0 + h) * 32 + r];
+        const int hb = rowhv[m0 + h] + r;
+        float b0[NKB], b1[NKB];
+#pragma unroll
+        for (int k = 0; k < NKB; ++k) { b0[k] = at[hb + off_main + k * 32]; b1[k] = at[hb + PL * XS + off_main + k * 32]; }
+#pragma unroll
+        for (int k = 0; k < NKB; ++k) {
+          acc[dzs][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[k], acc[dzs][k], 0, 0, 0);
+          acc[dzs + 1][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1[k], acc[dzs + 1][k], 0, 0, 0);
+        }
+        if (x0w) {
+#pragma unroll
+          for (int k = 0; k < NKB; ++k) accx[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, at[hb + off_x + k * 32], accx[k], 0, 0, 0);
+        }
+        if (x1w) {
+#pragma unroll
+          for (int k = 0; k < NKB; ++k) accx[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, at[hb + PL * XS + off_x + k * 32], accx[k], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NKB; ++k) {
+    const int kb = kg * NKB + k;
+    if (kb >= nkb) continue;
+    float *pb = part + (((size_t)g * gridDim.y + cb) * nkb + kb) * 27 * 1024;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      float *p = pb + (size_t)(d * 9 + wave) * 1024;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) p[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 32 + r] = acc[d][k][reg];
+    }
+    if (wave < 3) {
+      float *p = pb + (size_t)(wave * 9 + 8) * 1024;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) p[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 32 + r] = accx[k][reg];
+    }
+  }
+}
+
+hipError_t launch_wgrad_zs(const ConvArgs &a, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb, hipStream_t st) {
+  if (a.ntaps != 27 || a.stride != 1 || a.par || a.ups || a.Zo != 2 || a.Zs != 2 || a.by * a.bx > 32 || a.Ys != a.Yo || a.Xs != a.Xo ||
+      G < 1 || (a.C0 & 3) || (a.C1 & 3))
+    return hipErrorInvalidValue;
+  const size_t lds = ((size_t)64 + 64 * 32 + (size_t)2 * (a.by + 2) * (a.bx + 2) * 64) * 4;
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(wgrad_zs_kernel, dim3((unsigned)G, (unsigned)ncb, (unsigned)((nkb + 1) / 2)), dim3(512), lds, st, a, dy, dy_cs, part, G, nkb);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
 // Parity-form weight gradient of the upsample convs (see launch_wgrad_par).  grid (G * 8, ncb, nkb).
 // --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void wgrad_par_kernel(const ConvArgs a, const float *__restrict__ dy, int dy_cs,
