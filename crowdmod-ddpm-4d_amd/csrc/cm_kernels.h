@@ -243,6 +243,7 @@ hipError_t launch_wgrad_par(const ConvArgs &a, const float *dy, int dy_cs, float
 // two real planes only (a row block never multiplies its padding plane), coordinates are arithmetic (no table loads in
 // the tile loop), every load of a tile is issued in one batch; wave w owns in-plane tap q = w of every z tap, wave dz the
 // ninth one (q = 8) of z tap dz.  Partials in wgrad_reduce's layout part[G][ncb][nkb][27][32 co][32 ci].
+bool wgrad_zs_ok(const ConvArgs &a);
 hipError_t launch_wgrad_zs(const ConvArgs &a, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb, hipStream_t st);
 
 // Deferred per-sample voxel sums of the backward pass (bias gradient and the broadcast time-embedding term of every

@@ -267,49 +267,83 @@ __global__ __launch_bounds__(512, 2) void wgrad_zs_kernel(const ConvArgs a, cons
 #pragma unroll
     for (int j = 0; j < 16; ++j) accx[k][j] = 0.f;
   const int ntile = a.B * a.nty * a.ntx;
-  for (int tile = g; tile < ntile; tile += G) {
+  // Global loads of a tile are issued one tile AHEAD (registers), so that they complete under the previous tile's
+  // matrix phase -- one workgroup per CU (8 accumulator blocks per wave), nothing else would cover their latency.
+  constexpr int NH = 5;                        // halo float4 per thread (host: HV * 8 * NKB <= 512 * NH)
+  f32x4 dyv, hvv[NH];
+  auto issue = [&](int tile) {
     int tt = tile;
     const int tx = tt % a.ntx; tt /= a.ntx;
     const int ty = tt % a.nty;
     const int b = tt / a.nty;
     const int y0 = ty * a.by, x0 = tx * a.bx;
-    __syncthreads();
-    // dY rows (plane z in row block z)
     {
       const int m = tid >> 3, q = tid & 7;       // 64 rows x 8 channel quads = 512 items
       const int z = m >> 5, rr = m & 31;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      dyv = f32x4{0.f, 0.f, 0.f, 0.f};
       if (rr < nrow) {
         const int oy = y0 + rr / a.bx, ox = x0 + rr % a.bx, co = cb * 32 + 4 * q;
         if (oy < a.Yo && ox < a.Xo && co < a.Co) {
           const float *p = dy + ((((size_t)b * 2 + z) * a.Yo + oy) * a.Xo + ox) * dy_cs + co;
-          if (co + 3 < a.Co) v = *reinterpret_cast<const f32x4 *>(p);
-          else { v[0] = p[0]; v[1] = co + 1 < a.Co ? p[1] : 0.f; v[2] = co + 2 < a.Co ? p[2] : 0.f; }
+          if (co + 3 < a.Co) dyv = *reinterpret_cast<const f32x4 *>(p);
+          else { dyv[0] = p[0]; dyv[1] = co + 1 < a.Co ? p[1] : 0.f; dyv[2] = co + 2 < a.Co ? p[2] : 0.f; }
         }
       }
-      *reinterpret_cast<f32x4 *>(&dyt[m * 32 + 4 * q]) = v;
     }
-    // the two real planes of the conv's input with their in-plane halo (activation recomputed as the forward stages it)
-    for (int i = tid; i < HV * 8 * NKB; i += 512) {
-      const int hv = i / (8 * NKB), q = i - hv * (8 * NKB);
-      const int hz = hv / PL, rem = hv - hz * PL, hy = rem / HX, hx = rem - hy * HX;
-      const int cy = y0 + hy - 1, cx = x0 + hx - 1;
-      const int c = kg * XS + 4 * q;
-      f32x4 w = {0.f, 0.f, 0.f, 0.f};
-      if (c < Ctot && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs) {
-        const size_t off = (((size_t)b * 2 + hz) * a.Ys + cy) * a.Xs + cx;
-        w = (c < a.C0) ? *reinterpret_cast<const f32x4 *>(a.src0 + off * a.C0 + c)
-                       : *reinterpret_cast<const f32x4 *>(a.src1 + off * a.C1 + (c - a.C0));
-        if (a.gn) {
-          const float *gp = a.gn + (size_t)b * 2 * Ctot + c;
-          w = w * *reinterpret_cast<const f32x4 *>(gp) + *reinterpret_cast<const f32x4 *>(gp + Ctot);
-          if (a.silu) { w[0] *= sigmoid_f(w[0]); w[1] *= sigmoid_f(w[1]); w[2] *= sigmoid_f(w[2]); w[3] *= sigmoid_f(w[3]); }
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+      const int i = tid + 512 * u;
+      hvv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < HV * 8 * NKB) {
+        const int hv = i / (8 * NKB), q = i - hv * (8 * NKB);
+        const int hz = hv / PL, rem = hv - hz * PL, hy = rem / HX, hx = rem - hy * HX;
+        const int cy = y0 + hy - 1, cx = x0 + hx - 1;
+        const int c = kg * XS + 4 * q;
+        if (c < Ctot && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs) {
+          const size_t off = (((size_t)b * 2 + hz) * a.Ys + cy) * a.Xs + cx;
+          hvv[u] = (c < a.C0) ? *reinterpret_cast<const f32x4 *>(a.src0 + off * a.C0 + c)
+                             : *reinterpret_cast<const f32x4 *>(a.src1 + off * a.C1 + (c - a.C0));
         }
-        if (a.pm) w = w * *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + c);
       }
-      *reinterpret_cast<f32x4 *>(&at[hv * XS + 4 * q]) = w;
     }
+  };
+  // activation of the staged input as the forward applies it, then the LDS image; out-of-grid / padding entries stay zero
+  auto commit = [&](int tile) {
+    int tt = tile;
+    const int tx = tt % a.ntx; tt /= a.ntx;
+    const int ty = tt % a.nty;
+    const int b = tt / a.nty;
+    const int y0 = ty * a.by, x0 = tx * a.bx;
+    *reinterpret_cast<f32x4 *>(&dyt[(tid >> 3) * 32 + 4 * (tid & 7)]) = dyv;
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+      const int i = tid + 512 * u;
+      if (i < HV * 8 * NKB) {
+        const int hv = i / (8 * NKB), q = i - hv * (8 * NKB);
+        const int rem = hv % PL, hy = rem / HX, hx = rem - hy * HX;
+        const int cy = y0 + hy - 1, cx = x0 + hx - 1;
+        const int c = kg * XS + 4 * q;
+        f32x4 w = hvv[u];
+        if (c < Ctot && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs) {
+          if (a.gn) {
+            const float *gp = a.gn + (size_t)b * 2 * Ctot + c;
+            w = w * *reinterpret_cast<const f32x4 *>(gp) + *reinterpret_cast<const f32x4 *>(gp + Ctot);
+            if (a.silu) { w[0] *= sigmoid_f(w[0]); w[1] *= sigmoid_f(w[1]); w[2] *= sigmoid_f(w[2]); w[3] *= sigmoid_f(w[3]); }
+          }
+          if (a.pm) w = w * *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + c);
+        } else {
+          w = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        *reinterpret_cast<f32x4 *>(&at[hv * XS + 4 * q]) = w;
+      }
+    }
+  };
+  if (g < ntile) issue(g);
+  for (int tile = g; tile < ntile; tile += G) {
+    __syncthreads();                           // previous tile's operands have been read
+    commit(tile);
     __syncthreads();
+    if (tile + G < ntile) issue(tile + G);     // in flight under this tile's matrix phase
     // plane z uses the z taps dz = 1 - z, 2 - z ... i.e. z = 0: dz in {1, 2} (source planes 0, 1), z = 1: dz in {0, 1}
 #pragma unroll
     for (int z = 0; z < 2; ++z) {
@@ -357,12 +391,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_zs_kernel(const ConvArgs a, cons
   }
 }
 
+bool wgrad_zs_ok(const ConvArgs &a) {
+  return a.ntaps == 27 && a.stride == 1 && !a.par && !a.ups && a.Zo == 2 && a.Zs == 2 && a.by * a.bx <= 32 && a.Ys == a.Yo && a.Xs == a.Xo &&
+         !(a.C0 & 3) && !(a.C1 & 3) && (size_t)2 * (a.by + 2) * (a.bx + 2) * 16 <= 512 * 5 &&
+         ((size_t)64 + 64 * 32 + (size_t)2 * (a.by + 2) * (a.bx + 2) * 64) * 4 <= 64 * 1024;
+}
+
 hipError_t launch_wgrad_zs(const ConvArgs &a, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb, hipStream_t st) {
+  if (!wgrad_zs_ok(a)) return hipErrorInvalidValue;
   if (a.ntaps != 27 || a.stride != 1 || a.par || a.ups || a.Zo != 2 || a.Zs != 2 || a.by * a.bx > 32 || a.Ys != a.Yo || a.Xs != a.Xo ||
       G < 1 || (a.C0 & 3) || (a.C1 & 3))
     return hipErrorInvalidValue;
   const size_t lds = ((size_t)64 + 64 * 32 + (size_t)2 * (a.by + 2) * (a.bx + 2) * 64) * 4;
   if (lds > 64 * 1024) return hipErrorInvalidValue;
+  if ((size_t)2 * (a.by + 2) * (a.bx + 2) * 16 > 512 * 5) return hipErrorInvalidValue;   // halo items per thread (NH)
   hipLaunchKernelGGL(wgrad_zs_kernel, dim3((unsigned)G, (unsigned)ncb, (unsigned)((nkb + 1) / 2)), dim3(512), lds, st, a, dy, dy_cs, part, G, nkb);
   return hipGetLastError();
 }
