@@ -743,6 +743,88 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
   }
 }
 
+// --------------------------------------------------------------------------------------------------------------
+// 1x1x1 stride-1 convolution without output statistics (skip convs, attention in-projection, their data gradients;
+// layers.py:14,46,74) as a flat-row GEMM: no LDS, no barriers.  A wave owns 32 consecutive rows (sample, voxel) and
+// NB 32-channel output blocks; per 32-channel chunk it loads its A fragments straight from global memory (16 bytes
+// per lane and k8 step, GroupNorm affine / SiLU / dropout multiplier applied in registers), the packed weight
+// fragments of the chunk, and issues 16 NB MFMAs.  The generic kernel stages a per-sample halo tile through LDS with
+// two barriers per chunk for the same 16 MFMAs per block: these launches were latency-bound at 25-55 us.
+// --------------------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256) void conv1x1_flat_kernel(const ConvArgs a, long long N, int V) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const long long row0 = ((long long)blockIdx.x * 4 + wave) * 32;
+  if (row0 >= N) return;                          // (wave-uniform; no barriers in this kernel)
+  const int nt = blockIdx.y;
+  const long long n = row0 + r, nn = n < N ? n : N - 1;
+  const int b = (int)(nn / V);
+  const int Ctot = a.C0 + a.C1;
+  const int n0 = a.C0 >> 5, nchunks = n0 + (a.C1 >> 5);
+  const f32x4 *wt = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * nchunks * 4 * NB * 64 + lane;
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float *src;
+    int Cs, c0, cg0;
+    if (ch < n0) { src = a.src0; Cs = a.C0; c0 = ch * 32; cg0 = c0; }
+    else { src = a.src1; Cs = a.C1; c0 = (ch - n0) * 32; cg0 = a.C0 + c0; }
+    const float *ap = src + (size_t)nn * Cs + c0 + 4 * h;
+    f32x4 av[4], wv[4][NB];
+#pragma unroll
+    for (int k8 = 0; k8 < 4; ++k8) av[k8] = *reinterpret_cast<const f32x4 *>(ap + 8 * k8);
+#pragma unroll
+    for (int k8 = 0; k8 < 4; ++k8)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) wv[k8][nb] = wt[((size_t)(ch * 4 + k8) * NB + nb) * 64];
+    if (a.gn) {
+      const float *g = a.gn + (size_t)b * 2 * Ctot + cg0 + 4 * h;
+#pragma unroll
+      for (int k8 = 0; k8 < 4; ++k8) {
+        av[k8] = av[k8] * *reinterpret_cast<const f32x4 *>(g + 8 * k8) + *reinterpret_cast<const f32x4 *>(g + Ctot + 8 * k8);
+        if (a.silu) { av[k8][0] = silu_f(av[k8][0]); av[k8][1] = silu_f(av[k8][1]); av[k8][2] = silu_f(av[k8][2]); av[k8][3] = silu_f(av[k8][3]); }
+      }
+    }
+    if (a.pm) {
+      const float *pmp = a.pm + (size_t)b * a.pm_stride + cg0 + 4 * h;
+#pragma unroll
+      for (int k8 = 0; k8 < 4; ++k8) av[k8] = av[k8] * *reinterpret_cast<const f32x4 *>(pmp + 8 * k8);
+    }
+#pragma unroll
+    for (int k8 = 0; k8 < 4; ++k8)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k8][jj], wv[k8][nb][jj], acc[nb], 0, 0, 0);
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int co = (nt * NB + nb) * 32 + r;
+    if (co >= a.Co) continue;
+    const float bias = a.bias[co];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const long long orow = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (orow < N) {
+        float v = acc[nb][reg] + bias;
+        if (a.resid) v += a.resid[(size_t)orow * a.res_cs + co];
+        a.out[(size_t)orow * a.out_cs + co] = v;
+      }
+    }
+  }
+}
+
+bool conv1x1_flat_ok(const ConvArgs &a, int NB) {
+  return a.ntaps == 1 && a.td == 1 && a.stride == 1 && !a.par && !a.ups && a.CK == 32 && !(a.C0 & 31) && !(a.C1 & 31) && !a.stat_part &&
+         a.ks <= 1 && !a.temb && !a.s2w && !a.f16 && (NB == 1 || NB == 2) && a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo &&
+         !(conv_dbg_flags() & 65536);
+}
+
 size_t conv_lds_bytes(const ConvArgs &a, int MB, int NB) {
   const int HZ = (a.bz - 1) * a.stride + a.td;
   const int HY = (a.by - 1) * a.stride + a.td;
@@ -839,6 +921,14 @@ int conv_dbg_flags() {
 
 hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
   const int dbg = conv_dbg_flags();
+  if (conv1x1_flat_ok(a_in, NB)) {
+    const int V = a_in.Zo * a_in.Yo * a_in.Xo;
+    const long long N = (long long)a_in.B * V;
+    const dim3 grid((unsigned)((N + 127) / 128), (unsigned)((a_in.Co + 32 * NB - 1) / (32 * NB)));
+    if (NB == 1) hipLaunchKernelGGL(conv1x1_flat_kernel<1>, grid, dim3(256), 0, st, a_in, N, V);
+    else hipLaunchKernelGGL(conv1x1_flat_kernel<2>, grid, dim3(256), 0, st, a_in, N, V);
+    return hipGetLastError();
+  }
   static const int stg = getenv("CM_CONV_STAGGER") ? atoi(getenv("CM_CONV_STAGGER")) : -1;
   ConvArgs a = a_in;
   a.dbg = dbg;
