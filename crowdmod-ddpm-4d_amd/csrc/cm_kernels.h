@@ -322,6 +322,14 @@ hipError_t launch_time_bwd(const TimeBwdArgs &a, hipStream_t st);
 hipError_t launch_adam(float *p, const float *g, float *m, float *v, long long n, float lr, float b1, float b2,
                        float eps, float wd, int step, hipStream_t st);
 hipError_t launch_gather_pack(const float *W, const int *idx, int nk, float *packed, long long n, hipStream_t st);
+// Winograd-transformed weights (cm_conv_wino.hip layout, pack_wino) re-derived from the master parameters after an optimizer
+// step: element (n tile, chunk, xi_y, z tap, k half, xi_x, lane, jj) = sum_{dy,dx} G[xi_y][dy] G[xi_x][dx] W[idx27[(co, ci)][dz, dy, dx]].
+// idx27: [Co][Ci][27] indices into the flat parameter buffer (internal tap order; the data gradient passes the flipped /
+// transposed map).  One launch for all such tensors; 27 indices per (co, ci) pair instead of 9 (index, coefficient) terms per
+// packed element (48 elements per pair and z tap triple): ~20x less traffic than the generic gather.
+struct WinoPackJob { float *dst; const int *idx27; int Co, Ci, Ci_pad, pad; long long n; long long blk0; };
+hipError_t launch_wino_pack_jobs(const float *W, const WinoPackJob *jobs, const int *blk2job, long long nblocks, hipStream_t st);
+
 struct PackJob { float *dst; const int *idx; const float *coef; long long start; int nk; int pad; long long n; long long blk0; };   // coef: optional weights of the nk terms; n elements from workgroup blk0 on
 // blk2job[workgroup] = job index (each job owns ceil(n / 256) consecutive workgroups: no per-element search)
 hipError_t launch_gather_pack_jobs(const float *W, const PackJob *jobs, const int *blk2job, long long nblocks, hipStream_t st);

@@ -1498,6 +1498,52 @@ hipError_t launch_gather_pack_jobs(const float *W, const PackJob *jobs, const in
   return hipGetLastError();
 }
 
+__global__ void wino_pack_jobs_kernel(const float *__restrict__ W, const WinoPackJob *__restrict__ jobs, const int *__restrict__ blk2job) {
+  // one thread per (output channel, input channel, z tap) of the PADDED ranges: 9 taps in, the 16 components out
+  // (ci fastest across lanes: the 27-index rows of neighbouring lanes are adjacent, the stores of a component cover
+  // 16-byte runs of the packed layout)
+  const WinoPackJob jb = jobs[blk2job[blockIdx.x]];
+  const long long t = ((long long)blockIdx.x - jb.blk0) * 256 + threadIdx.x;
+  if (t >= jb.n) return;
+  const int nch = jb.Ci_pad / 16;
+  const int ci = (int)(t % jb.Ci_pad);
+  const int dz = (int)((t / jb.Ci_pad) % 3);
+  const int co = (int)(t / ((long long)jb.Ci_pad * 3));
+  float g[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) g[k] = 0.f;
+  if (co < jb.Co && ci < jb.Ci) {
+    const int *ip = jb.idx27 + ((size_t)co * jb.Ci + ci) * 27 + dz * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const int j = ip[k]; g[k] = j >= 0 ? W[j] : 0.f; }
+  }
+  const int nt = co >> 5, r = co & 31, chunk = ci >> 4, k8 = (ci >> 3) & 1, hh = (ci >> 2) & 1, jj = ci & 3;
+  float *base = jb.dst + ((((size_t)nt * nch + chunk) * 4) * 24 * 64 + hh * 32 + r) * 4 + jj;
+  // G = (1,0,0), (1/2,1/2,1/2), (1/2,-1/2,1/2), (0,0,1); terms in (dy, dx) order with the zero coefficients skipped
+  // (the summation order of the generic gather this replaces)
+  const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+#pragma unroll
+  for (int xy = 0; xy < 4; ++xy)
+#pragma unroll
+    for (int xx = 0; xx < 4; ++xx) {
+      float s = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float c = G[xy][dy] * G[xx][dx];
+          if (c != 0.f) s += c * g[dy * 3 + dx];
+        }
+      base[((size_t)xy * 24 + (dz * 2 + k8) * 4 + xx) * 64 * 4] = s;
+    }
+}
+
+hipError_t launch_wino_pack_jobs(const float *W, const WinoPackJob *jobs, const int *blk2job, long long nblocks, hipStream_t st) {
+  if (nblocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(wino_pack_jobs_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, W, jobs, blk2job);
+  return hipGetLastError();
+}
+
 hipError_t launch_gather_pack(const float *W, const int *idx, int nk, float *packed, long long n, hipStream_t st) {
   hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, idx, nk, packed, n);
   return hipGetLastError();
