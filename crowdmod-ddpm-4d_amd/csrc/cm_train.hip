@@ -448,35 +448,53 @@ __global__ __launch_bounds__(256) void wgrad_par_kernel(const ConvArgs a, const 
     const int b = tt / a.ntz;
     const int z0 = tz * a.bz, y0 = ty * a.by, x0 = tx * a.bx;
     __syncthreads();
+    // All global loads of the tile first (registers), then the LDS image: a load -> LDS-store loop costs one memory
+    // round trip per iteration (12 of them per tile here: 25 us per tile against 4 us of MFMAs).
+    constexpr int NDY = 5, NHA = 8;              // dY / halo float4 per thread (host: TM * 8 <= 256 * NDY, HV * 8 <= 256 * NHA)
+    f32x4 dyv[NDY], hav[NHA];
     // dY rows of this class: output voxel 2 i + p of low-resolution voxel i
-    for (int i = tid; i < TM * 8; i += 256) {
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+      const int i = tid + 256 * u;
       const int m = i >> 3, q = i & 7;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < nbox) {
+      dyv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < TM * 8 && m < nbox) {
         const int x = m % a.bx, qq = m / a.bx, y = qq % a.by, z = qq / a.by;
         const int iz = z0 + z, iy = y0 + y, ix = x0 + x;
         const int co = cb * 32 + 4 * q;
         if (iz < a.Zs && iy < a.Ys && ix < a.Xs && co < a.Co) {
           const float *p = dy + ((((size_t)b * a.Zo + 2 * iz + pz) * a.Yo + 2 * iy + py) * a.Xo + 2 * ix + px) * dy_cs + co;
-          if (co + 3 < a.Co) v = *reinterpret_cast<const f32x4 *>(p);
-          else { v[0] = p[0]; v[1] = co + 1 < a.Co ? p[1] : 0.f; v[2] = co + 2 < a.Co ? p[2] : 0.f; }
+          if (co + 3 < a.Co) dyv[u] = *reinterpret_cast<const f32x4 *>(p);
+          else { dyv[u][0] = p[0]; dyv[u][1] = co + 1 < a.Co ? p[1] : 0.f; dyv[u][2] = co + 2 < a.Co ? p[2] : 0.f; }
         }
       }
-      *reinterpret_cast<f32x4 *>(&dyt[m * 32 + 4 * q]) = v;
     }
     // low-resolution input halo, origin i0 + p - 1 (zero outside the grid = the padding of the upsampled tensor)
-    for (int i = tid; i < HV * 8; i += 256) {
+#pragma unroll
+    for (int u = 0; u < NHA; ++u) {
+      const int i = tid + 256 * u;
       const int hv = i >> 3, q = i & 7;
-      const int hx = hv % HX, qq = hv / HX, hy = qq % HY, hz = qq / HY;
-      const int cz = z0 + hz + pz - 1, cy = y0 + hy + py - 1, cx = x0 + hx + px - 1;
-      const int c = ci0 + 4 * q;
-      f32x4 w = {0.f, 0.f, 0.f, 0.f};
-      if (c < Ctot && cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs) {
-        const size_t off = (((size_t)b * a.Zs + cz) * a.Ys + cy) * a.Xs + cx;
-        w = (c < a.C0) ? *reinterpret_cast<const f32x4 *>(a.src0 + off * a.C0 + c)
-                       : *reinterpret_cast<const f32x4 *>(a.src1 + off * a.C1 + (c - a.C0));
+      hav[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < HV * 8) {
+        const int hx = hv % HX, qq = hv / HX, hy = qq % HY, hz = qq / HY;
+        const int cz = z0 + hz + pz - 1, cy = y0 + hy + py - 1, cx = x0 + hx + px - 1;
+        const int c = ci0 + 4 * q;
+        if (c < Ctot && cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs) {
+          const size_t off = (((size_t)b * a.Zs + cz) * a.Ys + cy) * a.Xs + cx;
+          hav[u] = (c < a.C0) ? *reinterpret_cast<const f32x4 *>(a.src0 + off * a.C0 + c)
+                             : *reinterpret_cast<const f32x4 *>(a.src1 + off * a.C1 + (c - a.C0));
+        }
       }
-      *reinterpret_cast<f32x4 *>(&at[hv * 32 + 4 * q]) = w;
+    }
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+      const int i = tid + 256 * u;
+      if (i < TM * 8) *reinterpret_cast<f32x4 *>(&dyt[(i >> 3) * 32 + 4 * (i & 7)]) = dyv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NHA; ++u) {
+      const int i = tid + 256 * u;
+      if (i < HV * 8) *reinterpret_cast<f32x4 *>(&at[(i >> 3) * 32 + 4 * (i & 7)]) = hav[u];
     }
     __syncthreads();
 #pragma unroll 2
@@ -515,7 +533,7 @@ hipError_t launch_wgrad_par(const ConvArgs &a, const float *dy, int dy_cs, float
   if (!a.par || a.gn || a.pm || a.ups || G < 1 || (a.C0 & 3) || (a.C1 & 3) || a.Zo != 2 * a.Zs || a.Yo != 2 * a.Ys || a.Xo != 2 * a.Xs)
     return hipErrorInvalidValue;
   const int nbox = a.bz * a.by * a.bx, TM = (nbox + 1) & ~1, HV = (a.bz + 1) * (a.by + 1) * (a.bx + 1);
-  if (TM > 256) return hipErrorInvalidValue;
+  if (TM > 160 || HV > 256) return hipErrorInvalidValue;   // staging registers: 5 dY + 8 halo float4 per thread
   const size_t lds = std::max<size_t>(((size_t)((TM + 3) & ~3) + (size_t)TM * 32 + (size_t)HV * 32) * 4, (size_t)3 * 1024 * 4);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(wgrad_par_kernel, dim3((unsigned)G * 8, (unsigned)ncb, (unsigned)nkb), dim3(256), lds, st, a, dy, dy_cs, part, G);
@@ -546,28 +564,48 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const ConvArgs a, const 
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
   for (long long ch = blockIdx.x; ch < nchunk; ch += G) {
     const long long n0 = ch * TM;
-    __syncthreads();
-    for (int i = tid; i < TM * 8; i += 256) {
+    // every global load of the chunk first (registers), then activation + LDS image (a load -> store loop would pay one
+    // memory round trip per iteration: 4 + 4 NKB of them)
+    f32x4 dyv[4], xv[4 * NKB];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 256 * u;
       const int m = i >> 3, q = i & 7;
       const long long n = n0 + m;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      dyv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (n < N) {
         const int co = cb * 32 + 4 * q;
         const float *p = dy + (size_t)n * dy_cs + co;
-        if (co + 3 < a.Co) v = *reinterpret_cast<const f32x4 *>(p);
-        else { v[0] = co < a.Co ? p[0] : 0.f; v[1] = co + 1 < a.Co ? p[1] : 0.f; v[2] = co + 2 < a.Co ? p[2] : 0.f; }
+        if (co + 3 < a.Co) dyv[u] = *reinterpret_cast<const f32x4 *>(p);
+        else { dyv[u][0] = co < a.Co ? p[0] : 0.f; dyv[u][1] = co + 1 < a.Co ? p[1] : 0.f; dyv[u][2] = co + 2 < a.Co ? p[2] : 0.f; }
       }
-      *reinterpret_cast<f32x4 *>(&dyt[m * 32 + 4 * q]) = v;
     }
-    for (int i = tid; i < TM * 8 * NKB; i += 256) {
+#pragma unroll
+    for (int u = 0; u < 4 * NKB; ++u) {
+      const int i = tid + 256 * u;
       const int m = i / (8 * NKB), q = i - m * (8 * NKB);
       const long long n = n0 + m;
       const int c = kg * XS + 4 * q;
-      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      xv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (n < N && c < Ctot)
+        xv[u] = (c < a.C0) ? *reinterpret_cast<const f32x4 *>(a.src0 + (size_t)n * a.C0 + c)
+                           : *reinterpret_cast<const f32x4 *>(a.src1 + (size_t)n * a.C1 + (c - a.C0));
+    }
+    __syncthreads();                             // previous chunk's tiles consumed
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 256 * u;
+      *reinterpret_cast<f32x4 *>(&dyt[(i >> 3) * 32 + 4 * (i & 7)]) = dyv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4 * NKB; ++u) {
+      const int i = tid + 256 * u;
+      const int m = i / (8 * NKB), q = i - m * (8 * NKB);
+      const long long n = n0 + m;
+      const int c = kg * XS + 4 * q;
+      f32x4 w = xv[u];
       if (n < N && c < Ctot) {
         const int b = (int)(n / V);
-        w = (c < a.C0) ? *reinterpret_cast<const f32x4 *>(a.src0 + (size_t)n * a.C0 + c)
-                       : *reinterpret_cast<const f32x4 *>(a.src1 + (size_t)n * a.C1 + (c - a.C0));
         if (a.gn) {
           const float *gp = a.gn + (size_t)b * 2 * Ctot + c;
           w = w * *reinterpret_cast<const f32x4 *>(gp) + *reinterpret_cast<const f32x4 *>(gp + Ctot);
@@ -669,35 +707,56 @@ __global__ __launch_bounds__(256) void wgrad_pack_kernel(const WgradPackArgs a, 
     const int tz = tt % a.ntz;
     const int b = tt / a.ntz;
     const int z0 = tz * a.bz, y0 = ty * a.by, x0 = tx * a.bx;
-    __syncthreads();                           // previous tile consumed (and rowhv written)
-    // wide rows (activation recomputed as the forward stages it)
-    for (int i = tid; i < TM * 8; i += 256) {
+    // all global loads of the tile first (registers), then activation + LDS image (see wgrad_par_kernel)
+    constexpr int NWD = 8, NNA = 5;              // wide / narrow float4 per thread (host: TM <= 256, HV * CN / 4 <= 256 * NNA)
+    f32x4 wv[NWD], nv[NNA];
+#pragma unroll
+    for (int u = 0; u < NWD; ++u) {
+      const int i = tid + 256 * u;
       const int m = i >> 3, q = i & 7;
-      const int x = m % a.bx, qq = m / a.bx, y = qq % a.by, z = qq / a.by;
-      const int cz = z0 + z, cy = y0 + y, cx = x0 + x;
-      f32x4 w = {0.f, 0.f, 0.f, 0.f};
-      if (cz < a.Z && cy < a.Y && cx < a.X) {
-        w = *reinterpret_cast<const f32x4 *>(a.wide + ((((size_t)b * a.Z + cz) * a.Y + cy) * a.X + cx) * a.wide_cs + 4 * q);
-        if (a.gn) {
+      wv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < TM * 8) {
+        const int x = m % a.bx, qq = m / a.bx, y = qq % a.by, z = qq / a.by;
+        const int cz = z0 + z, cy = y0 + y, cx = x0 + x;
+        if (cz < a.Z && cy < a.Y && cx < a.X)
+          wv[u] = *reinterpret_cast<const f32x4 *>(a.wide + ((((size_t)b * a.Z + cz) * a.Y + cy) * a.X + cx) * a.wide_cs + 4 * q);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NNA; ++u) {
+      const int i = tid + 256 * u;
+      nv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < HV * (CN / 4)) {
+        const int hv = i / (CN / 4), q = i - hv * (CN / 4);
+        const int hx = hv % HX, qq = hv / HX, hy = qq % HY, hz = qq / HY;
+        const int cz = z0 + hz - 1, cy = y0 + hy - 1, cx = x0 + hx - 1;
+        if (cz >= 0 && cz < a.Z && cy >= 0 && cy < a.Y && cx >= 0 && cx < a.X) {
+          const float *p = a.narrow + ((((size_t)b * a.Z + cz) * a.Y + cy) * a.X + cx) * a.narrow_cs + 4 * q;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) nv[u][e] = 4 * q + e < a.cn_valid ? p[e] : 0.f;
+        }
+      }
+    }
+    __syncthreads();                           // previous tile consumed (and rowhv written)
+#pragma unroll
+    for (int u = 0; u < NWD; ++u) {
+      const int i = tid + 256 * u;
+      if (i < TM * 8) {
+        const int m = i >> 3, q = i & 7;
+        const int x = m % a.bx, qq = m / a.bx, y = qq % a.by, z = qq / a.by;
+        f32x4 w = wv[u];
+        if (a.gn && z0 + z < a.Z && y0 + y < a.Y && x0 + x < a.X) {   // (rows outside the grid stay zero)
           const float *gp = a.gn + (size_t)b * 64 + 4 * q;
           w = w * *reinterpret_cast<const f32x4 *>(gp) + *reinterpret_cast<const f32x4 *>(gp + 32);
           if (a.silu) { w[0] *= sigmoid_f(w[0]); w[1] *= sigmoid_f(w[1]); w[2] *= sigmoid_f(w[2]); w[3] *= sigmoid_f(w[3]); }
         }
+        *reinterpret_cast<f32x4 *>(&wt[m * 32 + 4 * q]) = w;
       }
-      *reinterpret_cast<f32x4 *>(&wt[m * 32 + 4 * q]) = w;
     }
-    // narrow halo (zero outside the grid = the conv's zero padding, and beyond the valid channels)
-    for (int i = tid; i < HV * (CN / 4); i += 256) {
-      const int hv = i / (CN / 4), q = i - hv * (CN / 4);
-      const int hx = hv % HX, qq = hv / HX, hy = qq % HY, hz = qq / HY;
-      const int cz = z0 + hz - 1, cy = y0 + hy - 1, cx = x0 + hx - 1;
-      f32x4 w = {0.f, 0.f, 0.f, 0.f};
-      if (cz >= 0 && cz < a.Z && cy >= 0 && cy < a.Y && cx >= 0 && cx < a.X) {
-        const float *p = a.narrow + ((((size_t)b * a.Z + cz) * a.Y + cy) * a.X + cx) * a.narrow_cs + 4 * q;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = 4 * q + e < a.cn_valid ? p[e] : 0.f;
-      }
-      *reinterpret_cast<f32x4 *>(&nt[hv * CN + 4 * q]) = w;
+    for (int u = 0; u < NNA; ++u) {
+      const int i = tid + 256 * u;
+      if (i < HV * (CN / 4)) *reinterpret_cast<f32x4 *>(&nt[(i / (CN / 4)) * CN + 4 * (i % (CN / 4))]) = nv[u];
     }
     __syncthreads();
 #pragma unroll 2
@@ -735,7 +794,7 @@ __global__ __launch_bounds__(256) void wgrad_pack_kernel(const WgradPackArgs a, 
 
 hipError_t launch_wgrad_pack(const WgradPackArgs &a, int CN, int G, hipStream_t st) {
   const int TM = a.bz * a.by * a.bx, HV = (a.bz + 2) * (a.by + 2) * (a.bx + 2);
-  if (TM > 256 || (TM & 1) || (CN != 4 && CN != 8) || a.cn_valid > CN || G < 1) return hipErrorInvalidValue;
+  if (TM > 256 || (TM & 1) || (CN != 4 && CN != 8) || a.cn_valid > CN || G < 1 || HV * (CN / 4) > 256 * 5) return hipErrorInvalidValue;
   const size_t lds = std::max<size_t>(((size_t)((TM + 3) & ~3) + (size_t)TM * 32 + (size_t)HV * CN) * 4, (size_t)3 * 1024 * 4);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   if (CN == 4) hipLaunchKernelGGL(wgrad_pack_kernel<4>, dim3(G), dim3(256), lds, st, a, G);
