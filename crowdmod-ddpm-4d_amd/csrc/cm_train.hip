@@ -1088,31 +1088,50 @@ __device__ __forceinline__ float gnb_dy(const GnbArgs &a, int b, int c, int Ctot
 }
 
 __global__ __launch_bounds__(256) void gnb_reduce_kernel(const GnbArgs a) {
-  __shared__ float sh[512];
+  // thread = (channel quad of a 32-channel block, one of 32 voxel lanes): float4 loads, the per-(sample, channel) rows in
+  // registers; lanes merged through LDS in lane order
+  __shared__ f32x4 sh[2][256];
   const int sl = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int Ctot = a.C0 + a.C1;
   const int vs = (a.V + a.nsl - 1) / a.nsl, v0 = sl * vs, v1 = min(a.V, v0 + vs);
+  const int q = tid & 7, vl = tid >> 3;
   for (int cbase = 0; cbase < Ctot; cbase += 32) {
-    const int c = cbase + (tid & 31), vl = tid >> 5;
-    float s1 = 0.f, s2 = 0.f;
+    const int c = cbase + 4 * q;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     if (c < Ctot) {
       const float *xp; int Cx, cc;
       if (c < a.C0) { xp = a.x0; Cx = a.C0; cc = c; } else { xp = a.x1; Cx = a.C1; cc = c - a.C0; }
-      for (int v = v0 + vl; v < v1; v += 8) {
+      const float *mrp = a.mr + (size_t)b * 2 * Ctot + c;
+      const f32x4 mu = *reinterpret_cast<const f32x4 *>(mrp), rstd = *reinterpret_cast<const f32x4 *>(mrp + Ctot);
+      f32x4 pm = {1.f, 1.f, 1.f, 1.f}, gs = {0.f, 0.f, 0.f, 0.f}, gh = {0.f, 0.f, 0.f, 0.f};
+      if (a.pm) pm = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + c);
+      if (a.silu) {
+        const float *gnp = a.gn + (size_t)b * 2 * Ctot + c;
+        gs = *reinterpret_cast<const f32x4 *>(gnp); gh = *reinterpret_cast<const f32x4 *>(gnp + Ctot);
+      }
+      for (int v = v0 + vl; v < v1; v += 32) {
         const size_t row = (size_t)b * a.V + v;
-        float xh;
-        const float d = gnb_dy(a, b, c, Ctot, xp[row * Cx + cc], a.dA[row * a.dA_cs + c], xh);
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(xp + row * Cx + cc);
+        f32x4 d = *reinterpret_cast<const f32x4 *>(a.dA + row * a.dA_cs + c);
+        const f32x4 xh = (x - mu) * rstd;
+        if (a.pm) d = d * pm;
+        if (a.silu) {
+          const f32x4 y = gs * x + gh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float sg = sigmoid_f(y[e]); d[e] *= sg * (1.0f + y[e] * (1.0f - sg)); }
+        }
         s1 += d;
         s2 += d * xh;
       }
     }
-    sh[tid] = s1; sh[256 + tid] = s2;
+    sh[0][tid] = s1; sh[1][tid] = s2;
     __syncthreads();
-    if (tid < 32 && c < Ctot) {
-      float t1 = 0.f, t2 = 0.f;
-      for (int l = 0; l < 8; ++l) { t1 += sh[l * 32 + tid]; t2 += sh[256 + l * 32 + tid]; }
+    if (tid < 8 && c < Ctot) {
+      f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+      for (int l = 0; l < 32; ++l) { t1 += sh[0][l * 8 + tid]; t2 += sh[1][l * 8 + tid]; }
       float *p = a.part + (((size_t)b * a.nsl + sl) * Ctot + c) * 2;
-      p[0] = t1; p[1] = t2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { p[2 * e] = t1[e]; p[2 * e + 1] = t2[e]; }
     }
     __syncthreads();
   }
@@ -1152,21 +1171,34 @@ __global__ __launch_bounds__(256) void gnb_finalize_kernel(const GnbArgs a) {
 }
 
 __global__ __launch_bounds__(256) void gnb_apply_kernel(const GnbArgs a) {
-  const int Ctot = a.C0 + a.C1;
-  const long long total = (long long)a.B * a.V * Ctot;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  // one channel QUAD of one row per thread (float4 loads / stores; 32-bit index arithmetic): the scalar form spent most
+  // of its instructions on a 64-bit division and ten 4-byte loads per element
+  const int Ctot = a.C0 + a.C1, Q = Ctot >> 2;
+  const unsigned total = (unsigned)a.B * (unsigned)a.V * (unsigned)Q;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)(i % Ctot);
-  const long long row = i / Ctot;
-  const int b = (int)(row / a.V);
+  const unsigned row = i / (unsigned)Q;
+  const int c = (int)(i - row * (unsigned)Q) * 4;
+  const int b = (int)(row / (unsigned)a.V);
   const float *xp; float *gp; int Cx, cc, accf;
   if (c < a.C0) { xp = a.x0; gp = a.g0; Cx = a.C0; cc = c; accf = a.acc0; }
   else { xp = a.x1; gp = a.g1; Cx = a.C1; cc = c - a.C0; accf = a.acc1; }
-  float xh;
-  const float d = gnb_dy(a, b, c, Ctot, xp[row * Cx + cc], a.dA[row * a.dA_cs + c], xh);
-  const float dx = a.coef[((size_t)b * 3 + 0) * Ctot + c] * d - a.coef[((size_t)b * 3 + 1) * Ctot + c] -
-                   xh * a.coef[((size_t)b * 3 + 2) * Ctot + c];
-  float *o = gp + row * Cx + cc;
+  const f32x4 x = *reinterpret_cast<const f32x4 *>(xp + (size_t)row * Cx + cc);
+  f32x4 d = *reinterpret_cast<const f32x4 *>(a.dA + (size_t)row * a.dA_cs + c);
+  const float *mrp = a.mr + (size_t)b * 2 * Ctot + c;
+  const f32x4 mu = *reinterpret_cast<const f32x4 *>(mrp), rstd = *reinterpret_cast<const f32x4 *>(mrp + Ctot);
+  const f32x4 xh = (x - mu) * rstd;
+  if (a.pm) d = d * *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + c);
+  if (a.silu) {
+    const float *gnp = a.gn + (size_t)b * 2 * Ctot + c;
+    const f32x4 y = *reinterpret_cast<const f32x4 *>(gnp) * x + *reinterpret_cast<const f32x4 *>(gnp + Ctot);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float sg = sigmoid_f(y[e]); d[e] *= sg * (1.0f + y[e] * (1.0f - sg)); }
+  }
+  const float *cf = a.coef + (size_t)b * 3 * Ctot + c;
+  const f32x4 dx = *reinterpret_cast<const f32x4 *>(cf) * d - *reinterpret_cast<const f32x4 *>(cf + Ctot) -
+                   xh * *reinterpret_cast<const f32x4 *>(cf + 2 * Ctot);
+  f32x4 *o = reinterpret_cast<f32x4 *>(gp + (size_t)row * Cx + cc);
   *o = accf ? *o + dx : dx;
 }
 
@@ -1174,7 +1206,8 @@ hipError_t launch_gn_backward(const GnbArgs &a, hipStream_t st) {
   const int Ctot = a.C0 + a.C1;
   hipLaunchKernelGGL(gnb_reduce_kernel, dim3(a.nsl, a.B), dim3(256), 0, st, a);
   hipLaunchKernelGGL(gnb_finalize_kernel, dim3(a.B), dim3(256), (size_t)(2 * Ctot + 2 * a.groups) * sizeof(float), st, a);
-  const long long total = (long long)a.B * a.V * Ctot;
+  const long long total = (long long)a.B * a.V * (Ctot / 4);
+  if ((a.C0 & 3) || (a.C1 & 3) || (a.dA_cs & 3) || total >= (1ll << 31)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gnb_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
   return hipGetLastError();
 }
