@@ -6,6 +6,8 @@
 // implicit-GEMM kernel (cm_conv.hip) with transposed / flipped packed weights.
 #include "cm_kernels.h"
 
+#include <cstdint>
+
 namespace cm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1217,7 +1219,19 @@ hipError_t launch_gn_backward(const GnbArgs &a, hipStream_t st) {
 // --------------------------------------------------------------------------------
 // dst[b][v][c] (+)= src[b][v][c]   (channels-last, possibly different channel strides)
 __global__ void add_into_kernel(float *__restrict__ dst, int dcs, const float *__restrict__ src, int scs, int C,
-                                long long rows, int accumulate) {
+                                long long rows, int accumulate, int vec) {
+  // vec: one channel quad of one row per thread (float4, 32-bit index arithmetic; the host checked strides, size and
+  // pointer alignment); scalar form otherwise
+  if (vec) {
+    const unsigned Q = (unsigned)(C >> 2);
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (unsigned)rows * Q) return;
+    const unsigned row = i / Q, c = (i - row * Q) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)row * scs + c);
+    f32x4 *o = reinterpret_cast<f32x4 *>(dst + (size_t)row * dcs + c);
+    *o = accumulate ? *o + v : v;
+    return;
+  }
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= rows * C) return;
   const int c = (int)(i % C);
@@ -1229,8 +1243,10 @@ __global__ void add_into_kernel(float *__restrict__ dst, int dcs, const float *_
 
 hipError_t launch_add_into(float *dst, int dcs, const float *src, int scs, int C, long long rows, int accumulate,
                            hipStream_t st) {
-  hipLaunchKernelGGL(add_into_kernel, dim3((unsigned)((rows * C + 255) / 256)), dim3(256), 0, st, dst, dcs, src, scs,
-                     C, rows, accumulate);
+  const bool vec = !((C | dcs | scs) & 3) && rows * (C >> 2) < (1ll << 31) && !(reinterpret_cast<uintptr_t>(dst) & 15) &&
+                   !(reinterpret_cast<uintptr_t>(src) & 15);
+  const long long n = vec ? rows * (C >> 2) : rows * C;
+  hipLaunchKernelGGL(add_into_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, dcs, src, scs, C, rows, accumulate, vec ? 1 : 0);
   return hipGetLastError();
 }
 
