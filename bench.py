@@ -40,10 +40,28 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma
 F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide: dense f16/bf16 MFMA peak (the headline figures with sparsity are 2x)
 
 
-def load_cfg():
+def load_cfg(path=None):
     from crowdmod_ddpm_4d_amd import config as cfgmod
-    cfg = cfgmod.getYamlConfig(os.path.join(ROOT, "config", "ATC.yml"))
+    path = path or os.path.join("config", "ATC.yml")
+    cfg = cfgmod.getYamlConfig(path if os.path.isabs(path) else os.path.join(ROOT, path))
     return cfg, cfgmod.resolve(cfg, "DDPM-UNet")
+
+
+def self_launch(gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (one per GPU, RCCL
+    rendezvous on 127.0.0.1) before this process has touched the GPU, relay rank 0's JSON line and the exit code.
+    (Never re-exec: a process that initialised HIP must not be replaced, and this parent never initialises it.)"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def csrc_sha16():
@@ -170,7 +188,9 @@ def main():
     ap.add_argument("--channels", type=int, default=4)
     ap.add_argument("--mode", choices=("sample", "train"), default="sample")
     ap.add_argument("--dtype", choices=("f32", "f16"), default="f32", help="matrix-core operand type of the 3x3x3 convs")
-    ap.add_argument("--grid", type=str, default=None, help="HxW instead of config/ATC.yml's 12x36 (e.g. 24x72, 28x24)")
+    ap.add_argument("--grid", type=str, default=None, help="HxW instead of the config's grid (e.g. 24x72)")
+    ap.add_argument("--config", type=str, default=None, help="YAML instead of config/ATC.yml (e.g. config/HERMES-CR-120.yml = "
+                    "BASELINE configs[3]'s per-GPU shard; its own JSON line)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--lanes", type=int, default=1, help="batch lanes on separate HIP streams inside one rank (CM_LANES; 2 measured "
@@ -186,8 +206,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+        if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+            raise SystemExit(self_launch(a.gpus))      # parent of the N ranks; has not touched torch.cuda / HIP
         raise SystemExit(f"WORLD_SIZE={world} but --gpus={a.gpus}")
 
     import torch
@@ -211,7 +231,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    cfg, res = load_cfg()
+    cfg, res = load_cfg(a.config)
     if a.grid:
         H, W = (int(v) for v in a.grid.lower().split("x"))
         cfg.MACROPROPS.ROWS, cfg.MACROPROPS.COLS = H, W
@@ -219,7 +239,6 @@ def main():
         res = cfgmod.resolve(cfg, "DDPM-UNet")
     Cn, B = a.channels, (a.batch or 64)
     model = DDPM_model(cfg, "DDPM-UNet", Cn, device=local_rank, seed=42)
-    model.denoiser.max_batch = B
     if a.dtype != "f32":
         model.denoiser.set_precision(a.dtype)
     sampler = DDPM(timesteps=res.timesteps, scale=res.scale, device=local_rank)
@@ -288,16 +307,18 @@ def main():
             "kernel": "all 3x3x3 conv launches: conv_wino_kernel (Winograd F(2x2,3x3) over the in-plane axes, full- and "
                       "half-resolution layers), conv_mfma_kernel<*,*,27|8> (direct / parity-form upsample / stride 2 / "
                       "K-split quarter resolution), conv_first_kernel, conv_smalln_kernel",
-            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-            "frac": ach / peak, "traffic": hbm_traffic(),
-            "executed_tflops": exe, "executed_frac": exe / peak,
+            "bound": "mfma", "achieved": exe, "peak": peak, "unit": "TFLOP/s",
+            "frac": exe / peak, "traffic": hbm_traffic(),
+            "algorithmic_tflops": ach, "algorithmic_frac": ach / peak,
             "launches": int(cnt[0]), "avg_launch_us": ms[0] * 1e3 / max(1, cnt[0]),
             "measured_with": "an extra run of the same K steps, same launch configuration, with HIP events around every "
                              "launch on its launch stream (events inside the timed runs would add ~1.5 us per launch to "
-                             "`value`); `achieved` counts ALGORITHMIC FLOPs (2 x 27 x Ci x Co per voxel, as PyTorch counts "
-                             "the reference's nn.Conv3d), `executed_*` the matrix-core FLOPs actually issued (Winograd and "
-                             "parity forms issue fewer): frac > executed_frac is the algorithmic saving; rocprofv3 "
-                             "--kernel-trace --stats of this command: profiles/round2_kernel_stats.csv",
+                             "`value`); `achieved` / `frac` count the matrix-core FLOPs actually ISSUED (Winograd, parity and "
+                             "z-split forms issue fewer than the direct form) -- the hardware fraction; `algorithmic_*` counts "
+                             "2 x 27 x Ci x Co per voxel as PyTorch counts the reference's nn.Conv3d and can exceed 1 (it "
+                             "is the algorithmic saving, not a roof); rocprofv3 --kernel-trace --stats of this command: "
+                             "profiles/round3_kernel_stats.csv",
+            "executed_gflop_per_launch": conv3_exec / max(1, cnt[0]) / 1e9,
             "algorithmic_gflop_per_launch": conv3_flops / max(1, cnt[0]) / 1e9,
             "class_ms_per_step": {k: ms[i] / steps for i, k in enumerate(
                 ["conv3x3x3", "conv1x1x1_gemm", "groupnorm_stats", "attention_block", "elementwise"])},
@@ -307,16 +328,22 @@ def main():
         dist.barrier()
 
     cpu = None
-    if rank == 0 and world == 1 and a.cpu_budget > 0 and a.dtype == "f32" and not a.grid:
+    if rank == 0 and world == 1 and a.cpu_budget > 0 and a.dtype == "f32" and not a.grid and not a.config:
         cpu = cpu_baseline(res, Cn, B, a.cpu_budget)
 
     if rank == 0:
-        wl = "config/ATC.yml sampling (BASELINE configs[1])" if not a.grid and a.dtype == "f32" else \
-            "config/ATC.yml UNet on the %s grid, %s matrix-core operands (BASELINE configs[4] shape)" % (a.grid or "12x36", a.dtype)
+        cfg_name = os.path.relpath(os.path.join(ROOT, a.config), ROOT) if a.config else "config/ATC.yml"
+        known = {("config/ATC.yml", (12, 36)): "BASELINE configs[1]",
+                 ("config/HERMES-CR-120.yml", (28, 24)): "BASELINE configs[3], one GPU's shard",
+                 ("config/ATC_synthetic.yml", (24, 72)): "BASELINE configs[4], one GPU's shard",
+                 ("config/ATC.yml", (24, 72)): "BASELINE configs[4] shape"}
+        tag = known.get((cfg_name, (res.rows, res.cols)), "not a BASELINE config")
+        wl = "%s sampling on the %dx%d grid, %s matrix-core operands (%s)" % (cfg_name, res.rows, res.cols, a.dtype, tag)
         out = {
             "metric": "denoise-steps/sec (UNet fwd + sampler update) at ATC [B,4,T,H,W]",
             "value": world * steps / elapsed,
-            "unit": "denoise-steps/s (each over a batch of %d chains)" % B,
+            "unit": "denoise-steps/s, aggregate over %d GPU%s under weak scaling (every GPU advances its own batch of %d chains "
+                    "per step)" % (world, "" if world == 1 else "s", B),
             "n_gpus": world, "steps": steps, "warmup": a.warmup,
             "ms_per_step": elapsed / steps * 1e3,
             "repeat_ms_per_step": [t / steps * 1e3 for t in times],

@@ -57,6 +57,11 @@ def _rebuild_tensor_v2(storage, storage_offset, size, stride, requires_grad=Fals
     numel = 1
     for v in size:
         numel *= v
+    if numel > flat.size:
+        # a broadcast (stride-0) view stays inside the storage whatever its size: torch keeps it a view, this reader
+        # materialises it -- a crafted (1 << 40,) x stride 0 entry must not become a terabyte host allocation
+        raise pickle.UnpicklingError(f"tensor view of {numel} elements over a storage of {flat.size}: a state_dict "
+                                     f"tensor never has more elements than its storage")
     if numel > 0:
         last = storage_offset + sum((n - 1) * st for n, st in zip(size, stride))
         if last >= flat.size:

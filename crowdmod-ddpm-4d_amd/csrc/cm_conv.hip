@@ -915,7 +915,7 @@ static void conv_dbg_report(const ConvArgs &a, int MB, int NB, int F, dim3 grid,
 
 int conv_dbg_override = -1;
 int conv_dbg_flags() {
-  static const int env = getenv("CM_CONV_DBG") ? atoi(getenv("CM_CONV_DBG")) : 0;  // ablation switches (perf studies only)
+  static const int env = cm::diag_env("CM_CONV_DBG") ? atoi(cm::diag_env("CM_CONV_DBG")) : 0;  // ablation switches (perf studies only)
   return conv_dbg_override >= 0 ? conv_dbg_override : env;
 }
 
@@ -929,7 +929,7 @@ hipError_t launch_conv(const ConvArgs &a_in, int MB, int NB, hipStream_t st) {
     else hipLaunchKernelGGL(conv1x1_flat_kernel<2>, grid, dim3(256), 0, st, a_in, N, V);
     return hipGetLastError();
   }
-  static const int stg = getenv("CM_CONV_STAGGER") ? atoi(getenv("CM_CONV_STAGGER")) : -1;
+  static const int stg = cm::diag_env("CM_CONV_STAGGER") ? atoi(cm::diag_env("CM_CONV_STAGGER")) : -1;
   ConvArgs a = a_in;
   a.dbg = dbg;
   if (stg >= 0) a.stagger = stg;

@@ -9,8 +9,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace cm {
+
+// Diagnostic environment switches (kernel ablations, tile experiments: DESIGN.md section 6) are read ONLY when
+// CM_DIAG=1 is set as well -- a stray CM_* variable in a production environment cannot change which kernels run or
+// what they compute.  Product switches read with plain getenv: CM_LANES, CM_USE_GRAPH, CM_LIB_PATH (Python side).
+inline const char *diag_env(const char *name) {
+  static const bool on = [] { const char *d = getenv("CM_DIAG"); return d && d[0] == '1' && d[1] == 0; }();
+  return on ? getenv(name) : nullptr;
+}
 
 // One implicit-GEMM convolution launch:  out[m][n] = sum_k A[m][k] * W[k][n]
 //   m = output voxel (b,z,y,x), n = output channel, k = (tap, input channel).

@@ -527,7 +527,7 @@ const TunedTile kTunedTiles[] = {
     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
 const TunedTile *find_tuned(const cm::ConvArgs &a, int NB /* 0: any */) {
-  static const bool off = getenv("CM_NO_TUNED") != nullptr;
+  static const bool off = cm::diag_env("CM_NO_TUNED") != nullptr;
   if (off) return nullptr;
   for (const TunedTile *t = kTunedTiles; t->ntaps; ++t)
     if (t->ntaps == a.ntaps && t->stride == a.stride && t->par == a.par && t->Ci == a.C0 + a.C1 && t->Co == a.Co &&
@@ -574,7 +574,7 @@ void pick_tile_first(Op &op) {
 void pick_tile(Op &op, int B) {
   cm::ConvArgs &a = op.ca;
   const int NB = op.NB;
-  static const int force_mb = getenv("CM_FORCE_MB") ? atoi(getenv("CM_FORCE_MB")) : 0;
+  static const int force_mb = cm::diag_env("CM_FORCE_MB") ? atoi(cm::diag_env("CM_FORCE_MB")) : 0;
   const int osd = a.par ? 2 : 1;  // parity mode tiles the low-resolution source grid
   const int Zo = a.Zo / osd, Yo = a.Yo / osd, Xo = a.Xo / osd;
   const int vox = Zo * Yo * Xo;
@@ -660,7 +660,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   a.Zo = s.out->Z; a.Yo = s.out->Y; a.Xo = s.out->X;
   a.ntaps = s.ntaps; a.stride = s.stride; a.ups = s.ups;
   a.td = s.ntaps == 27 ? 3 : 1; a.par = 0; a.wpar_stride = 0;
-  const bool parity = s.ups && s.ntaps == 27 && !getenv("CM_NO_PARITY_UPCONV");
+  const bool parity = s.ups && s.ntaps == 27 && !cm::diag_env("CM_NO_PARITY_UPCONV");
   if (parity) { a.ups = 0; a.par = 1; a.td = 2; a.ntaps = 8; }
   a.out = s.out->d; a.out_cs = s.out->C; a.Co = s.Co;
   a.temb = s.temb; a.temb_stride = m->nproj; a.tidx = m->tbuf;
@@ -681,21 +681,21 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   {
     int wz = 0, wy = 0, wx = 0;
     op.wino = s.ntaps == 27 && s.stride == 1 && !s.ups && a.C0 % 16 == 0 && a.C1 % 16 == 0 && s.Co % 32 == 0 && s.Co == s.out->C &&
-              s.ci_valid < 0 && s.out->V() > 64 && cm::conv_wino_pick(s.out->Z, s.out->Y, s.out->X, &wz, &wy, &wx) && !getenv("CM_NO_WINO");
+              s.ci_valid < 0 && s.out->V() > 64 && cm::conv_wino_pick(s.out->Z, s.out->Y, s.out->X, &wz, &wy, &wx) && !cm::diag_env("CM_NO_WINO");
   }
   // tiny-spatial layers are overhead-bound, not throughput-bound: fewer, fatter workgroups
   // (all 128 output channels per workgroup, K split over workgroups) amortise the per-workgroup
   // fixed costs over 4x the matrix work
   // (NB = 4 "fat" tiles -- all 128 output channels per workgroup -- spill ~80 VGPRs on the register-ring path and
   // measured no better than two NB = 2 workgroups: opt-in only)
-  if (s.ntaps == 27 && s.out->V() <= 64 && s.Co % 128 == 0 && getenv("CM_FAT_TILES")) op.NB = 4;
-  if (s.ntaps == 27 && s.out->V() <= 64 && getenv("CM_QR_NB")) op.NB = atoi(getenv("CM_QR_NB"));
+  if (s.ntaps == 27 && s.out->V() <= 64 && s.Co % 128 == 0 && cm::diag_env("CM_FAT_TILES")) op.NB = 4;
+  if (s.ntaps == 27 && s.out->V() <= 64 && cm::diag_env("CM_QR_NB")) op.NB = atoi(cm::diag_env("CM_QR_NB"));
   if (op.wino) op.NB = 1;
   if (s.ntaps == 27 && s.out->V() > 64 && !op.wino) {
     if (const TunedTile *t = find_tuned(a, 0)) op.NB = t->NB;
     // tuner policies (tools/tune_tiles.py): N blocking of the 64- / 128-channel 3x3x3 layers
-    if (s.Co == 64 && getenv("CM_NB64")) op.NB = atoi(getenv("CM_NB64"));
-    if (s.Co == 128 && getenv("CM_NB128")) op.NB = atoi(getenv("CM_NB128"));
+    if (s.Co == 64 && cm::diag_env("CM_NB64")) op.NB = atoi(cm::diag_env("CM_NB64"));
+    if (s.Co == 128 && cm::diag_env("CM_NB128")) op.NB = atoi(cm::diag_env("CM_NB128"));
   }
   const Param &w = P(m, s.wname);
   const Param &b = P(m, s.bname);
@@ -727,7 +727,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   }
   // the UNet's last conv (base -> C channels): vector-ALU kernel instead of a 32-wide MFMA tile
   if (s.ntaps == 27 && s.stride == 1 && !s.ups && s.Co <= 8 && !s.stats && !s.temb && !s.resid &&
-      !getenv("CM_NO_SMALLN")) {
+      !cm::diag_env("CM_NO_SMALLN")) {
     op.small_n = true;
     op.small_nco = s.Co <= 4 ? 4 : 8;
     const int nco = op.small_nco, nch = Ci_pad / a.CK;
@@ -749,7 +749,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   }
   // the UNet's first conv (C <= 8 data channels -> base): dedicated kernel, whole weight set in registers
   if (s.s0 == m->x8_act && s.ntaps == 27 && s.stride == 1 && !s.ups && !s.gn && !s.temb && !s.resid && !s.s1 &&
-      s.Co % 32 == 0 && Ci_ref <= 8 && !getenv("CM_NO_FIRSTK")) {
+      s.Co % 32 == 0 && Ci_ref <= 8 && !cm::diag_env("CM_NO_FIRSTK")) {
     op.first_k = true;
     op.first_cin = Ci_ref <= 4 ? 4 : 8;
     const int cin = op.first_cin, NS = 27 * cin / 2, hc = cin / 2, ntn = s.Co / 32;
@@ -770,7 +770,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   std::copy(b.host.begin(), b.host.end(), bp.begin());
   if (upload(m, bp, &db)) return 1;
   a.wfrag = dw; a.bias = db;
-  if (s.stats && !getenv("CM_NO_FUSED_STATS")) op.stat_act = s.out;
+  if (s.stats && !cm::diag_env("CM_NO_FUSED_STATS")) op.stat_act = s.out;
   op.out_act = s.out;
   op.resid_act = s.resid;
   op.pm_off = s.pm_off;
@@ -785,10 +785,10 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   // more parallelism AND less weight traffic per workgroup is to split K over workgroups;
   // a second pass sums the partials in a fixed order and applies the epilogue.
   const int nchunks = a.nch0 + a.nch1;
-  static const int qr_vmax = getenv("CM_QR_VMAX") ? atoi(getenv("CM_QR_VMAX")) : 96;   // HERMES-CR-120 quarter resolution: 84 voxels
+  static const int qr_vmax = cm::diag_env("CM_QR_VMAX") ? atoi(cm::diag_env("CM_QR_VMAX")) : 96;   // HERMES-CR-120 quarter resolution: 84 voxels
   if (s.ntaps == 27 && !parity && a.CK == 32 && nchunks >= 2 && s.out->V() <= qr_vmax && s.Co <= 256 && s.Co == s.out->C &&
-      op.stat_act && !getenv("CM_NO_KSPLIT")) {
-    static const int qr_ks = getenv("CM_QR_KS") ? atoi(getenv("CM_QR_KS")) : 4;
+      op.stat_act && !cm::diag_env("CM_NO_KSPLIT")) {
+    static const int qr_ks = cm::diag_env("CM_QR_KS") ? atoi(cm::diag_env("CM_QR_KS")) : 4;
     op.ks = std::max(1, std::min(nchunks, s.out->V() > 64 ? std::min(qr_ks, 2) : qr_ks));   // (84 voxels: ks 2 3.06 ms, ks 4 3.12, none 3.16 per CR-120 step)
     const size_t need = (size_t)op.ks * m->cfg.max_batch * s.out->V() * s.Co;
     m->ks_scratch_floats = std::max(m->ks_scratch_floats, need);
@@ -797,7 +797,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   }
   // fuse the 1x1x1 skip conv when this conv runs on the 27-tap register-ring path without K split
   if (s.skip0 && s.ntaps == 27 && !parity && a.CK == 32 && !op.small_n && (!op.wino || op.NB == 1) && s.stride == 1 &&
-      s.skip0->C % 32 == 0 && (!s.skip1 || s.skip1->C % 32 == 0) && !getenv("CM_NO_FUSE_SKIP")) {
+      s.skip0->C % 32 == 0 && (!s.skip1 || s.skip1->C % 32 == 0) && !cm::diag_env("CM_NO_FUSE_SKIP")) {
     const Param &w2 = P(m, s.skip_w);
     const Param &b2 = P(m, s.skip_b);
     const int Ci2 = (int)w2.shape[1];
@@ -817,7 +817,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
 }
 
 void add_stats(cm_model *m, const Act *a) {
-  if (!getenv("CM_NO_FUSED_STATS")) return;  // the producing conv writes the statistics in its epilogue
+  if (!cm::diag_env("CM_NO_FUSED_STATS")) return;  // the producing conv writes the statistics in its epilogue
   Op op;
   op.kind = OP_STATS; op.cls = K_NORM; op.act = a; op.label = "stats(" + a->name + ")";
   m->ops.push_back(op);
@@ -934,7 +934,7 @@ int build_ops(cm_model *m) {
       // (cm_attn_block.hip) when the sample's tokens fit the LDS-resident design; the four generic ops above
       // stay in the list for the training forward (their activations feed the backward pass) and as fallback.
       const int nops = (int)m->ops.size();
-      if (cm::attn_block_ok(qkv->V(), b.cout, ATTN_HEADS, GN_GROUPS) && !getenv("CM_NO_FUSED_ATTN") && !getenv("CM_NO_FUSED_STATS")) {
+      if (cm::attn_block_ok(qkv->V(), b.cout, ATTN_HEADS, GN_GROUPS) && !cm::diag_env("CM_NO_FUSED_ATTN") && !cm::diag_env("CM_NO_FUSED_STATS")) {
         Op fb;
         fb.kind = OP_ATTNBLK; fb.cls = K_ATTN; fb.label = ap + " (fused block)";
         fb.ab_x = h2; fb.ab_out = h3; fb.S = qkv->V(); fb.E = b.cout;
@@ -1060,18 +1060,32 @@ int run_combine(cm_model *m, cm::CombineArgs &cb, hipStream_t st);
 int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   if (op.skip_if_fused && !m->train_fwd) return 0;  // absorbed by the block's conv_2 (inference plan)
   if (op.tuned_B < 0 && op.wino) {
-    cm::ConvArgs &a = op.ca;
+    // feasibility is known only with the launch geometry: a grid the Winograd tiles do not fit falls back to the
+    // direct kernel (its fragments `wfrag` are packed for every conv; NB = 1 was fixed before packing)
+    cm::ConvArgs a = op.ca;
     a.bs = 1;
-    if (!cm::conv_wino_pick(a.Zo, a.Yo, a.Xo, &a.bz, &a.by, &a.bx)) return fail("no Winograd tile for %s", op.label.c_str());
-    a.ntz = a.Zo / a.bz; a.nty = (a.Yo + a.by - 1) / a.by; a.ntx = (a.Xo + a.bx - 1) / a.bx;
-    op.MB = 4;                       // statistics slots per tile: the four (a, b) output sub-blocks
-    op.tuned_B = B;
-    if (!cm::conv_wino_ok(a)) return fail("Winograd tile does not fit %s", op.label.c_str());
+    bool ok = cm::conv_wino_pick(a.Zo, a.Yo, a.Xo, &a.bz, &a.by, &a.bx);
+    if (ok) {
+      a.ntz = a.Zo / a.bz; a.nty = (a.Yo + a.by - 1) / a.by; a.ntx = (a.Xo + a.bx - 1) / a.bx;
+      ok = cm::conv_wino_ok(a);
+    }
+    if (ok) {
+      op.ca = a;
+      op.MB = 4;                     // statistics slots per tile: the four (a, b) output sub-blocks
+      op.tuned_B = B;
+    } else {
+      op.wino = false;
+    }
   }
   if (op.tuned_B < 0 && op.first_k) {
+    const cm::ConvArgs keep = op.ca;
     pick_tile_first(op);
-    op.tuned_B = B;
-    if (!cm::conv_first_ok(op.ca, op.first_cin)) return fail("first-conv tile does not fit");
+    if (cm::conv_first_ok(op.ca, op.first_cin)) {
+      op.tuned_B = B;
+    } else {
+      op.ca = keep;                  // e.g. more columns than the full-X tile holds: the direct kernel takes it
+      op.first_k = false;
+    }
   }
   if (op.tuned_B < 0) {
     pick_tile(op, TUNE_BATCH);
@@ -1165,7 +1179,7 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
 // Second pass of a K-split layer (or the head sum of the fused attention block): with the consumer's GroupNorm
 // finalisation fused when run_ops found one waiting (m->fin_next) and the shapes allow it.
 int run_combine(cm_model *m, cm::CombineArgs &cb, hipStream_t st) {
-  static const bool no_fuse = getenv("CM_NO_FUSE_GNFIN") != nullptr;
+  static const bool no_fuse = cm::diag_env("CM_NO_FUSE_GNFIN") != nullptr;
   const Op *f = m->fin_next;
   m->fin_done = false;
   if (f && !no_fuse && (!f->g1 || f->g1->V() == cb.V)) {
@@ -1853,7 +1867,7 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
       hipStream_t ls = sts[ln];
       if (k == 0) CM_HIP(cm::launch_fill_t(m->tbuf + b0, Bn, t, ls));
       // two lanes (CM_LANES=2): optionally start the second one when the first is part-way through its first step
-      static const double lane_phase = getenv("CM_LANE_PHASE") ? atof(getenv("CM_LANE_PHASE")) : 0.0;   // measured: no offset is best (1.909 ms vs 1.916 / 1.920 / 1.941 at 0.3 / 0.5 / 0.7)
+      static const double lane_phase = cm::diag_env("CM_LANE_PHASE") ? atof(cm::diag_env("CM_LANE_PHASE")) : 0.0;   // measured: no offset is best (1.909 ms vs 1.916 / 1.920 / 1.941 at 0.3 / 0.5 / 0.7)
       if (k == 0 && lanes == 2 && lane_phase > 0) {
         if (ln == 0) m->mid_at = (int)(lane_phase * (double)m->ops.size());
         else CM_HIP(hipStreamWaitEvent(ls, m->ev_half, 0));

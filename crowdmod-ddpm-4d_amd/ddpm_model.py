@@ -364,7 +364,6 @@ class DDPM_model:
             idx = np.repeat(idx, chunk)[:samples_per_batch]            # repeat_interleave, then the first samples_per_batch
             pasts, futures = past_test[idx], future_test[idx]
             nb = len(idx)
-            self.denoiser.max_batch = max(self.denoiser.max_batch, nb)
             logging.info("Computing sampling on batch %d: %d chains (%d pasts x %d repeats)", count + 1, nb, -(-nb // chunk), chunk)
             if r.sampler == "DDPM":
                 x, _ = self._generate_ddpm(pasts, sampler, nb)

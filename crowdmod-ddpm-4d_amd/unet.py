@@ -37,6 +37,7 @@ class UNet:
         self.condition = condition
         self.device = int(device)
         self.max_batch = int(max_batch)
+        self._native_max_batch = 0
         self.training = False
         self._shapes = spec.param_shapes(self.cfg)
         # random init with torch-default ranges (the reference's nn.Module ctor does the same)
@@ -122,7 +123,9 @@ class UNet:
     def ensure(self, rows: int, cols: int, past_len: int, future_len: int, batch: int):
         """Create (or re-create) the native model for this tensor geometry."""
         geom = (rows, cols, past_len, future_len)
-        if self._handle is not None and self._geom == geom and batch <= self.max_batch:
+        # compare against the capacity the NATIVE handle was created with, not the Python attribute: a caller that
+        # raised `max_batch` after the handle existed must get a new handle, not a rejected launch
+        if self._handle is not None and self._geom == geom and max(batch, self.max_batch) <= self._native_max_batch:
             return self._handle
         self._release()
         self.max_batch = max(self.max_batch, batch)
@@ -149,7 +152,7 @@ class UNet:
         except Exception:
             L.cm_model_destroy(h)
             raise
-        self._handle, self._geom = h, geom
+        self._handle, self._geom, self._native_max_batch = h, geom, self.max_batch
         carry = getattr(self, "_carry_opt", None)
         if carry is not None:
             # the handle this one replaces was training: continue from its optimizer state

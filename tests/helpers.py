@@ -32,3 +32,23 @@ def loop_noise(tag, B, per, t):
 
 def load(name):
     return np.load(os.path.join(GOLDEN, name))
+
+
+def join_all(procs, timeout):
+    """Join child processes; a child that is still alive after `timeout` seconds (hung rendezvous, hung rank) is
+    terminated -- then killed -- before the caller asserts, so it cannot keep the GPU or the TCP port for the rest of
+    the pytest session.  Returns the exit codes (None never: a killed child reports its signal)."""
+    import time
+    deadline = time.monotonic() + timeout
+    try:
+        for p in procs:
+            p.join(timeout=max(0.0, deadline - time.monotonic()))
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+                p.join()
+    return [p.exitcode for p in procs]

@@ -13,7 +13,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import FULL_GRIDS, SEED_W, full_cfg, narrow_cfg
+from helpers import FULL_GRIDS, SEED_W, full_cfg, join_all, narrow_cfg
 
 pytestmark = pytest.mark.gpu
 
@@ -111,9 +111,7 @@ def test_two_processes_sharded_ddpm_sampling_equals_single_process(tmp_path, gb)
     ps = [ctx.Process(target=_sample_worker, args=(r, 2, port, gb, str(tmp_path))) for r in range(2)]
     for p in ps:
         p.start()
-    for p in ps:
-        p.join(timeout=600)
-        assert p.exitcode == 0
+    assert join_all(ps, 600) == [0, 0]
     single = np.load(tmp_path / "single.npy")
     assert np.isfinite(single).all() and single.shape == (gb, 3) + FULL_GRIDS["atc"] + (3,)
     for r in range(2):
@@ -163,9 +161,7 @@ def test_two_data_parallel_replicas_stay_identical(tmp_path):
     ps = [ctx.Process(target=_train_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
     for p in ps:
         p.start()
-    for p in ps:
-        p.join(timeout=600)
-        assert p.exitcode == 0
+    assert join_all(ps, 600) == [0, 0]
     a, b = np.load(tmp_path / "dp0.npz"), np.load(tmp_path / "dp1.npz")
     assert np.array_equal(a["hist"], b["hist"]) and float(a["lr"]) == float(b["lr"]) and len(a["hist"]) == 3
     assert np.array_equal(a["w"], b["w"]) and np.array_equal(a["b"], b["b"])
@@ -208,7 +204,6 @@ def test_two_stream_lanes_equal_the_single_lane_loop(tmp_path):
         out = str(tmp_path / f"lanes{lanes}.npy")
         p = ctx.Process(target=_lanes_worker, args=(lanes, out))
         p.start()
-        p.join(timeout=600)
-        assert p.exitcode == 0
+        assert join_all([p], 600) == [0]
         outs.append(np.load(out))
     assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])

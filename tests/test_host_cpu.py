@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from crowdmod_ddpm_4d_amd import checkpoint, config as cfgmod, distributed, native, prng, spec
-from helpers import load
+from helpers import join_all, load
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -185,7 +185,10 @@ def _tensor_pickle(size, stride, offset, numel=6):
     import struct
 
     def i4(v):
-        return b"J" + struct.pack("<i", v)
+        if -(1 << 31) <= v < (1 << 31):
+            return b"J" + struct.pack("<i", v)
+        raw = v.to_bytes((v.bit_length() + 8) // 8, "little", signed=True)     # LONG1
+        return b"\x8a" + bytes([len(raw)]) + raw
 
     def tup(vals):
         return b"(" + b"".join(i4(v) for v in vals) + b"t"
@@ -206,7 +209,9 @@ def _tensor_pickle(size, stride, offset, numel=6):
     ((2, 3), (-1, 1), 3, False),         # negative stride
     ((-2, 3), (3, 1), 0, False),         # negative size
     ((2, 3), (3, 1), -1, False),         # negative offset
-    ((1 << 20, 3), (0, 1), 0, True),     # broadcast view inside the storage is legal (3 MiB result)
+    ((2, 3), (0, 1), 0, True),           # broadcast view with no more elements than the storage: legal
+    ((1 << 20, 3), (0, 1), 0, False),    # broadcast view LARGER than its storage: would be materialised -> rejected
+    ((1 << 40,), (0,), 0, False),        # ... before a terabyte allocation, not after
     ((0, 3), (3, 1), 100, True),         # empty tensor: nothing is read
 ])
 def test_checkpoint_rejects_out_of_bounds_tensor_views(tmp_path, size, stride, offset, ok):
@@ -222,7 +227,7 @@ def test_checkpoint_rejects_out_of_bounds_tensor_views(tmp_path, size, stride, o
     if ok:
         w = checkpoint.load(p)["model"]["w"]
         assert w.shape == tuple(size)
-        if w.size and size == (2, 3):
+        if w.size and size == (2, 3) and stride == (3, 1):
             assert np.array_equal(w, np.arange(6, dtype=np.float32).reshape(2, 3))
     else:
         with pytest.raises(pickle.UnpicklingError):
@@ -423,9 +428,11 @@ def test_gradient_averaging_two_ranks_gloo():
     ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in ps:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in ps)
-    for p in ps:
-        p.join(timeout=60)
+    try:
+        res = sorted(q.get(timeout=120) for _ in ps)
+    finally:
+        codes = join_all(ps, 60)
+    assert codes == [0, 0]
     assert res == [(0, 1.5, 1.5), (1, 1.5, 1.5)]
 
 
@@ -476,9 +483,11 @@ def test_data_parallel_epoch_decisions_are_identical_on_every_rank():
     ps = [ctx.Process(target=_dp_control_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in ps:
         p.start()
-    res = sorted(q.get(timeout=180) for _ in ps)
-    for p in ps:
-        p.join(timeout=60)
+    try:
+        res = sorted(q.get(timeout=180) for _ in ps)
+    finally:
+        codes = join_all(ps, 60)
+    assert codes == [0, 0]
     (r0, n0, lrs0, lr0, t0), (r1, n1, lrs1, lr1, t1) = res
     assert n0 == n1 == 32          # NaN from epoch 30 on rank 1 only -> both stop after 3 NaN epochs
     assert lrs0 == lrs1 and len(lrs0) >= 1 and lr0 == lr1 < 5e-5

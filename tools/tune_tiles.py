@@ -94,7 +94,7 @@ def main():
     for grid in a.grids.split(","):
         for ch in a.channels.split(","):
             for nb64, nb128 in ((2, 2), (1, 1)):
-                env = dict(os.environ, CM_NO_TUNED="1", CM_NB64=str(nb64), CM_NB128=str(nb128), CM_LANES="1")
+                env = dict(os.environ, CM_DIAG="1", CM_NO_TUNED="1", CM_NB64=str(nb64), CM_NB128=str(nb128), CM_LANES="1")
                 out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f"{grid},{ch},{nb64},{nb128}",
                                       "--batch", str(a.batch), "--iters", str(a.iters)], env=env, capture_output=True, text=True)
                 if out.returncode != 0:
