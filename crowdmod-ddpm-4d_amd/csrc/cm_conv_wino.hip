@@ -24,6 +24,12 @@
 //     GroupNorm statistics of the block in the slot format of gn_finalize).
 #include "cm_kernels.h"
 
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
 namespace cm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -126,6 +132,26 @@ __device__ __forceinline__ void wino_skip_mfma(int n2, int c0s, const f32x4 (&sa
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) v = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[u][k8][jj], sw[u][k8][jj], v, 0, 0, 0);
     }
+}
+
+// one 32-channel chunk at a time (persistent kernel: its epilogue holds the NEXT tile's prefetched halo loads as well, so
+// the three-chunk batch above would not fit the register file)
+__device__ __forceinline__ void wino_skip_load1(const ConvArgs &a, int nt, int n2a, int n2, int c2, int svox, int lane,
+                                                f32x4 (&sa)[4], f32x4 (&sw)[4]) {
+  const int hh = lane >> 5;
+  const f32x4 *w2 = reinterpret_cast<const f32x4 *>(a.s2w) + (size_t)nt * n2 * 4 * 64 + lane;
+  const float *s2 = c2 < n2a ? a.s2src0 + (size_t)svox * a.s2C0 + c2 * 32 : a.s2src1 + (size_t)svox * a.s2C1 + (c2 - n2a) * 32;
+#pragma unroll
+  for (int k8 = 0; k8 < 4; ++k8) {
+    sa[k8] = *reinterpret_cast<const f32x4 *>(s2 + 8 * k8 + 4 * hh);
+    sw[k8] = w2[(size_t)(c2 * 4 + k8) * 64];
+  }
+}
+__device__ __forceinline__ void wino_skip_mfma1(const f32x4 (&sa)[4], const f32x4 (&sw)[4], f32x16 &v) {
+#pragma unroll
+  for (int k8 = 0; k8 < 4; ++k8)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) v = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[k8][jj], sw[k8][jj], v, 0, 0, 0);
 }
 
 // Tile = BZ planes x PY x PX patches (2x2 outputs each), ROWS = BZ * PY * PX <= 32 rows of the accumulator block
@@ -296,7 +322,13 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
     };
     if constexpr (TWO) {
       // step A: this chunk's halo voxels (loaded during the previous matrix phase) -> activated image R
-      if (a.gn && a.silu && !a.pm) {            // (workgroup-uniform: the plain ResnetBlock conv; no selects on the flags)
+      if (a.dbg & 128) {                        // diagnostic: plain copy instead of GroupNorm + SiLU
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {
+          const int v = (tid >> 2) + (NT / 4) * k;
+          if (v < RV) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = ald[k];
+        }
+      } else if (a.gn && a.silu && !a.pm) {     // (workgroup-uniform: the plain ResnetBlock conv; no selects on the flags)
 #pragma unroll
         for (int k = 0; k < RK; ++k) {
           const int v = (tid >> 2) + (NT / 4) * k;
@@ -354,7 +386,7 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
       }
     }
     if constexpr (!TWO) __syncthreads();    // previous chunk's fragments have been read
-    if (stager) {
+    if (stager && !(a.dbg & 1)) {
 #pragma unroll
       for (int k = 0; k < NR * 4; ++k) {                               // component xi = (2 hf + i) * 4 + j, k = i * 4 + j
         const int xi = HALF ? 8 * hf + k : k;
@@ -380,6 +412,7 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
       }
     }
     // ---- matrix phase: NG groups (z tap [, 8-channel half]) x 4 components ---------------------------------
+    if (a.dbg & 2) continue;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int dz = F16 ? g : g >> 1, k8 = F16 ? 0 : g & 1;
@@ -413,6 +446,10 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
   // ---- fused 1x1x1 skip convolution (ResnetBlock.match_input, layers.py:46,74; inference plan): issue the loads
   // of its operands now -- the RAW block input at this wave's 32 output voxels and the packed 1x1 weights -- so
   // that their latency hides behind the output transform; the MFMAs run on the finished sub-block below.
+  if (a.dbg & 4) {
+    if (acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 123.456f) a.out[0] = 1.f;   // keep the accumulators live
+    return;
+  }
   const int n2a = a.s2C0 >> 5, n2 = a.s2w ? (a.s2C0 + a.s2C1) >> 5 : 0;
   f32x4 sa[WINO_SKB][4], sw[WINO_SKB][4];
   int svox = 0;
@@ -450,6 +487,366 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
     }
   }
   wino_epilogue(a, v, outoff, nt, wave, lane, b0, bs, (((tz * a.nty + ty) * a.ntx) + tx) * 4 + wave, bias_pre, tv_pre);
+}
+
+// ================================================================================================================
+// Persistent two-step form (round 3).  Ablation of the kernel above on the full-resolution 32 -> 32 layer (78.7 us):
+// matrix phase 44.5 us, everything else 34.2 us -- and the two ADD (no overlap): all workgroups have the same duration, so
+// the whole chip marches through load burst -> staging -> matrix phase -> store burst in lock-step rounds, the
+// latency-bound parts (first-chunk loads, GroupNorm rows, index tables, output stores) never hide under another
+// workgroup's matrix phase, and every workgroup repeats ~1000 vector / ~670 scalar instructions of prologue and epilogue
+// for 192 matrix instructions.  Here a workgroup is (tile position p, sample lane g) and loops over the samples
+// b = g, g + G, ...:
+//   * the tile geometry (source offsets of the halo box, output offsets, ownership) comes from two host-built tables and
+//     is resolved ONCE per workgroup; per sample only scalar base pointers move (32-bit in-sample byte offsets);
+//   * the halo loads AND the GroupNorm scale / shift rows of the next chunk -- which may be the first chunk of the NEXT
+//     sample -- are issued before the current matrix phase: no cold start after the first tile, output stores of tile i
+//     drain under the staging of tile i + 1;
+//   * output exchange through LDS as 16-byte accesses (8 + 12 instead of 32 + 48 LDS instructions), store addresses as
+//     one 24-bit multiply-add each, a mask-free store / statistics path when the wave owns all of its 32 rows.
+// Same arithmetic in the same order as conv_wino_kernel<..., TWO = true>: results are bit-identical to it.
+// SKIP: the block's 1x1x1 skip convolution is contracted onto the finished sub-block (its own instantiation, so that the
+// plain layers do not carry its registers: with it in one body the kernel spilled ~100 registers).
+template <int BZ, int PY, int PX, bool F16, int NBW, bool SKIP>
+__global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArgs a, const int *__restrict__ tabA,
+                                                                  const int *__restrict__ tabO, int G) {
+  constexpr int NT = 256 * NBW;
+  constexpr int NP = PY * PX, ROWS = BZ * NP;
+  static_assert(ROWS <= 32 && ROWS > 16, "one (partly filled) 32-row accumulator block per frequency component");
+  constexpr int HZ = BZ + 2, UR = HZ * NP;
+  constexpr bool SWZ = !F16 && PY * PX == 4;
+  constexpr int CS = 16, S = F16 ? 12 : (SWZ ? CS : CS + 4);
+  constexpr int RYH = 2 * PY + 2, RXH = 2 * PX + 2, RV = HZ * RYH * RXH, RS_ = BZ == 8 ? 24 : 20;
+  constexpr int RK = (RV * 4 + NT - 1) / NT;
+  constexpr int NITEMS = HZ * NP * (CS / 4);
+  static_assert(NITEMS <= 256, "one staging item per thread");
+  constexpr int USZ = 16 * UR * S, XSZ = NBW * 4 * 2 * 16 * 64;
+  constexpr int UX = USZ > XSZ ? USZ : XSZ;          // U, later the exchange buffer: R must NOT overlap it (next tile's step A)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int *outoff = reinterpret_cast<int *>(lds);       // [4 sub-blocks (a, b)][32 rows] in-sample output voxel index or -1
+  float *U = lds + 128;
+  float *R = U + UX;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wv8 & 3, nbw = wv8 >> 2;
+  const int r = lane & 31, hh = lane >> 5;
+  const int g0 = blockIdx.x, p = blockIdx.y;
+  const int nt = blockIdx.z * NBW + nbw;
+  if (g0 >= a.B) return;
+  const int nc_epi = nt * 32 + r < a.Co ? nt * 32 + r : 0;
+  const float bias_pre = a.bias[nc_epi];
+
+  // ---- tile geometry from the tables (cm_conv_wino.hip: wino_tables) --------------------------------------------
+  if (tid < 128) outoff[tid] = tabO[p * 128 + tid];
+  int asoff[RK];
+  unsigned aok = 0;
+#pragma unroll
+  for (int k = 0; k < RK; ++k) asoff[k] = tabA[(p * RK + k) * (NT / 4) + (tid >> 2)];
+#pragma unroll
+  for (int k = 0; k < RK; ++k) {
+    aok |= (asoff[k] >= 0 ? 1u : 0u) << k;
+    asoff[k] = asoff[k] >= 0 ? asoff[k] : 0;
+  }
+  const int aq = tid & 3;
+  const bool stager = tid < NITEMS;
+  const int it = stager ? tid : 0;
+  const int quad = it & 3, patch = (it >> 2) % NP, zi = it / (4 * NP);
+  const int urow = zi * NP + patch;
+  float *const uw = U + (size_t)urow * S + (F16 ? 2 : 4) * (SWZ ? (quad ^ ((urow >> 2) & 3)) : quad);
+  const int rbase = ((zi * RYH + 2 * (patch / PX)) * RXH + 2 * (patch % PX)) * RS_ + 4 * quad;
+
+  const int n0 = a.C0 >> 4, nchunks = n0 + (a.C1 >> 4);
+  const int Ctot = a.C0 + a.C1;
+  const unsigned Vs = (unsigned)(a.Zs * a.Ys * a.Xs), Vo = (unsigned)(a.Zo * a.Yo * a.Xo);
+  constexpr int NG = F16 ? 3 : 6;
+  const f32x4 *wbase = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * nchunks * (4 * NG * 4 * 64) + wave * (NG * 4 * 64) + lane;
+  constexpr int RS = F16 ? 3 : 2;
+  static_assert(NG % RS == 0, "ring slots must line up at chunk boundaries");
+  f32x4 bq[RS][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) bq[0][x] = wbase[x * 64];
+
+  const int ar = min(r, ROWS - 1);
+  const float *arow = U + (size_t)(wave * 4) * UR * S + (size_t)ar * S + (SWZ ? 0 : 4 * hh);
+  // this lane's output rows of the epilogue: reg -> row (reg & 3) + 8 (reg >> 2) + 4 hh of sub-block `wave`
+  // (read once per workgroup after the table has landed, below)
+
+  // ---- loads of (sample b, chunk ch): halo voxels of the thread's step-A slots + the GroupNorm rows of its channel quad
+  f32x4 ald[RK], scn = {1.f, 1.f, 1.f, 1.f}, shn = {0.f, 0.f, 0.f, 0.f};
+  auto issue = [&](int b, int ch) {
+    const bool s0 = ch < n0;
+    const int Cn = s0 ? a.C0 : a.C1;
+    const float *base = (s0 ? a.src0 + ch * CS : a.src1 + (ch - n0) * CS) + (size_t)b * Vs * Cn;      // wave-uniform
+    const unsigned cb = (unsigned)Cn * 4u, aq16 = 16u * (unsigned)aq;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+      unsigned vo = (unsigned)asoff[k];
+      asm volatile("" : "+v"(vo));               // keep ONE copy of the offsets live (no hoisted per-source products)
+      ald[k] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(base) + (__umul24(vo, cb) + aq16));
+    }
+    if (a.gn) {
+      const float *gp = a.gn + (size_t)b * 2 * Ctot + (s0 ? ch * CS : a.C0 + (ch - n0) * CS);              // wave-uniform
+      scn = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(gp) + aq16);
+      shn = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(gp + Ctot) + aq16);
+    }
+  };
+  issue(g0, 0);
+  __syncthreads();                               // outoff visible
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  // this lane's output rows of the epilogue: reg -> row (reg & 3) + 8 (reg >> 2) + 4 hh of sub-block `wave` (re-read per tile:
+  // four 16-byte broadcast reads are cheaper than 16 registers held across the matrix phase)
+  const i32x4 *const op4 = reinterpret_cast<const i32x4 *>(outoff + wave * 32 + 4 * hh);
+  bool allv = true;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const i32x4 v4 = op4[2 * q];
+    allv = allv && v4[0] >= 0 && v4[1] >= 0 && v4[2] >= 0 && v4[3] >= 0;
+  }
+  const bool wave_all = __all(allv) && nt * 32 + 31 < a.Co;       // the wave owns all 32 rows x 32 channels: mask-free path
+  const int n = nt * 32 + r;
+  const bool nok = n < a.Co;
+  const int n2a = SKIP ? a.s2C0 >> 5 : 0, n2 = SKIP ? (a.s2C0 + a.s2C1) >> 5 : 0;
+  const int slot = p * 4 + wave;
+
+  for (int b = g0; b < a.B; b += G) {
+    const bool more_b = b + G < a.B;
+    const float tv_pre = a.temb ? a.temb[(size_t)a.tidx[b] * a.temb_stride + nc_epi] : 0.f;
+    f32x16 acc[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[x][i] = 0.f;
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+      // ---- step A: this chunk's halo voxels -> activated image R ------------------------------------------
+      const f32x4 sc1 = scn, sh1 = shn;
+      f32x4 pm1 = {1.f, 1.f, 1.f, 1.f};
+      if (a.pm) pm1 = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + (ch < n0 ? ch * CS : a.C0 + (ch - n0) * CS) + 4 * aq);
+      if (a.gn && a.silu && !a.pm) {
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {
+          const int v = (tid >> 2) + (NT / 4) * k;
+          f32x4 w = ald[k] * sc1 + sh1;
+          w[0] = silu_w(w[0]); w[1] = silu_w(w[1]); w[2] = silu_w(w[2]); w[3] = silu_w(w[3]);
+          if (!((aok >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (v < RV) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = w;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {
+          const int v = (tid >> 2) + (NT / 4) * k;
+          f32x4 w = ald[k];
+          if (a.gn) {
+            w = w * sc1 + sh1;
+            if (a.silu) { w[0] = silu_w(w[0]); w[1] = silu_w(w[1]); w[2] = silu_w(w[2]); w[3] = silu_w(w[3]); }
+          }
+          if (a.pm) w = w * pm1;
+          if (!((aok >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (v < RV) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = w;
+        }
+      }
+      __syncthreads();                          // R complete; every wave is past the previous matrix phase / exchange reads
+      // ---- step B: B^T d B of the item's 4x4 patch out of R ------------------------------------------------
+      if (stager) {
+        f32x4 d[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[i * 4 + j] = *reinterpret_cast<const f32x4 *>(R + rbase + (i * RXH + j) * RS_);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4 e0 = d[i * 4 + 0], e1 = d[i * 4 + 1], e2 = d[i * 4 + 2], e3 = d[i * 4 + 3];
+          d[i * 4 + 0] = pk_sub(e0, e2); d[i * 4 + 1] = e1 + e2; d[i * 4 + 2] = pk_sub(e2, e1); d[i * 4 + 3] = pk_sub(e1, e3);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j], e3 = d[3 * 4 + j];
+          d[0 * 4 + j] = pk_sub(e0, e2); d[1 * 4 + j] = e1 + e2; d[2 * 4 + j] = pk_sub(e2, e1); d[3 * 4 + j] = pk_sub(e1, e3);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          if constexpr (F16) {
+            const f16x4 hv = {(_Float16)d[k][0], (_Float16)d[k][1], (_Float16)d[k][2], (_Float16)d[k][3]};
+            *reinterpret_cast<f16x4 *>(uw + (size_t)k * UR * S) = hv;
+          } else {
+            *reinterpret_cast<f32x4 *>(uw + (size_t)k * UR * S) = d[k];
+          }
+        }
+      }
+      __syncthreads();
+      // ---- next chunk's loads (possibly the next sample's first chunk): in flight under this matrix phase -----
+      if (ch + 1 < nchunks) issue(b, ch + 1);
+      else if (more_b) issue(b + G, 0);
+      // ---- matrix phase: NG groups (z tap [, 8-channel half]) x 4 components, A fragments one group ahead -------
+      auto aread = [&](int g, f32x4 (&af)[4]) {
+        const int dz = F16 ? g : g >> 1, k8 = F16 ? 0 : g & 1;
+        const int acol = SWZ ? 4 * ((2 * k8 + hh) ^ (((ar >> 2) + dz) & 3)) : 8 * k8;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) af[x] = *reinterpret_cast<const f32x4 *>(arow + (size_t)x * UR * S + (size_t)dz * NP * S + acol);
+      };
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        {
+          const bool more = g < NG - 1 || ch + 1 < nchunks || more_b;
+          const int cn = g < NG - 1 ? ch : (ch + 1 < nchunks ? ch + 1 : 0);
+          const f32x4 *wn = wbase + (size_t)cn * (4 * NG * 4 * 64) + (size_t)(g < NG - 1 ? g + 1 : 0) * (4 * 64);
+          if (more) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) bq[(g + 1) % RS][x] = wn[x * 64];
+          }
+        }
+        f32x4 af[4];
+        aread(g, af);
+        if constexpr (F16) {
+#pragma unroll
+          for (int x = 0; x < 4; ++x)
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[x]), __builtin_bit_cast(f16x8, bq[g % RS][x]), acc[x], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+              acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x][jj], bq[g % RS][x][jj], acc[x], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- tile epilogue ---------------------------------------------------------------------------------------
+    // output transform: A^T = (1,1,1,0), (0,1,-1,-1) along x in registers, along y through LDS (16-byte accesses)
+    f32x16 t0 = acc[0] + acc[1] + acc[2];
+    f32x16 t1 = acc[1] - acc[2] - acc[3];
+    __syncthreads();                            // U is dead: reuse as the exchange buffer
+    f32x4 *const XC = reinterpret_cast<f32x4 *>(U) + (size_t)nbw * (4 * 2 * 4 * 64);   // [wave][blk 2][q 4][lane 64] float4
+    {
+      f32x4 *xb = XC + (size_t)(wave * 2) * 4 * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        xb[q * 64] = f32x4{t0[4 * q], t0[4 * q + 1], t0[4 * q + 2], t0[4 * q + 3]};
+        xb[(4 + q) * 64] = f32x4{t1[4 * q], t1[4 * q + 1], t1[4 * q + 2], t1[4 * q + 3]};
+      }
+    }
+    __syncthreads();
+    const int oa = wave >> 1, ob = wave & 1;
+    f32x16 v;
+    {
+      const f32x4 *p0 = XC + (size_t)(((oa + 0) * 2 + ob) * 4) * 64 + lane;       // oa = 0: waves 0,1,2 (+,+,+); oa = 1: waves 1,2,3 (+,-,-)
+      const f32x4 *p1 = XC + (size_t)(((oa + 1) * 2 + ob) * 4) * 64 + lane;
+      const f32x4 *p2 = XC + (size_t)(((oa + 2) * 2 + ob) * 4) * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 u0 = p0[q * 64], u1 = p1[q * 64], u2 = p2[q * 64];
+        const f32x4 w4 = oa == 0 ? (u0 + u1) + u2 : (u0 - u1) - u2;
+        v[4 * q] = w4[0]; v[4 * q + 1] = w4[1]; v[4 * q + 2] = w4[2]; v[4 * q + 3] = w4[3];
+      }
+    }
+    if constexpr (SKIP) {
+      // operands requested only now, one 32-channel chunk at a time (requesting them under the output transform, or double
+      // buffering them, was the register peak of the kernel and spilled into the chunk loop)
+      f32x4 sa[4], sw[4];
+      const int o = outoff[wave * 32 + r];
+      const int svox = (o >= 0 ? o : 0) + (int)(b * Vo);
+      for (int c2 = 0; c2 < n2; ++c2) {
+        wino_skip_load1(a, nt, n2a, n2, c2, svox, lane, sa, sw);
+        wino_skip_mfma1(sa, sw, v);
+      }
+    }
+    // bias, time-embedding row, residual, channels-last store, GroupNorm statistics (slot format of gn_finalize)
+    {
+      float *const outb = a.out + (size_t)b * Vo * a.out_cs;
+      const unsigned ocs4 = (unsigned)a.out_cs * 4u, n4 = (unsigned)(nok ? n : 0) * 4u;
+      int orow[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const i32x4 v4 = op4[2 * q];
+        orow[4 * q] = v4[0]; orow[4 * q + 1] = v4[1]; orow[4 * q + 2] = v4[2]; orow[4 * q + 3] = v4[3];
+      }
+      float rs[16];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) rs[reg] = v[reg] + bias_pre;
+      if (a.temb) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) rs[reg] += tv_pre;
+      }
+      if (a.resid) {
+        const float *const resb = a.resid + (size_t)b * Vo * a.res_cs;
+        const unsigned rcs4 = (unsigned)a.res_cs * 4u;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const unsigned oc = (unsigned)(orow[reg] >= 0 ? orow[reg] : 0);
+          rs[reg] += *reinterpret_cast<const float *>(reinterpret_cast<const char *>(resb) + (__umul24(oc, rcs4) + n4));
+        }
+      }
+      if (wave_all) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          *reinterpret_cast<float *>(reinterpret_cast<char *>(outb) + (__umul24((unsigned)orow[reg], ocs4) + n4)) = rs[reg];
+      } else {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if (nok && orow[reg] >= 0)
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(outb) + (__umul24((unsigned)orow[reg], ocs4) + n4)) = rs[reg];
+      }
+      if (a.stat_part) {
+        float s1 = 0.f, cnt = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if (orow[reg] >= 0) { s1 += rs[reg]; cnt += 1.f; }
+        s1 += __shfl_xor(s1, 32);
+        cnt += __shfl_xor(cnt, 32);
+        const float mean = cnt > 0.f ? s1 / cnt : 0.f;
+        float q = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if (orow[reg] >= 0) { const float dd = rs[reg] - mean; q += dd * dd; }
+        q += __shfl_xor(q, 32);
+        if (hh == 0 && nok) {
+          float *sp2 = a.stat_part + (((size_t)b * a.stat_ns + slot) * a.stat_C + n) * 2;
+          sp2[0] = mean;
+          sp2[1] = q;
+        }
+        if (lane == 0 && n == 0) a.stat_cnt[(size_t)b * a.stat_ns + slot] = cnt;
+      }
+    }
+  }
+}
+
+// Geometry tables of the persistent kernel for one (grid, tile) pair, `nth` = threads per workgroup:
+//   tabA[p][k][nth / 4]: in-sample SOURCE voxel index of halo voxel v = j + (nth / 4) k of tile position p, or -1
+//                        (zero padding, or v beyond the halo box);   tabO[p][4 (a, b)][32 rows]: in-sample OUTPUT voxel
+//   index of the row's (a, b) output, or -1 (row beyond the tile, or a patch a shifted last tile does not own).
+// p = (tz * nty + ty) * ntx + tx, the statistics-slot order of conv_wino_kernel.
+static void wino_tables(const ConvArgs &a, int nth, std::vector<int> &tA, std::vector<int> &tO) {
+  const int PY = a.by / 2, PX = a.bx / 2, BZ = a.bz, NP = PY * PX, ROWS = BZ * NP;
+  const int HZ = BZ + 2, RYH = 2 * PY + 2, RXH = 2 * PX + 2, RV = HZ * RYH * RXH;
+  const int RK = (RV * 4 + nth - 1) / nth, q4 = nth / 4;
+  const int ntp = a.ntz * a.nty * a.ntx;
+  const int pyt = a.Yo >> 1, pxt = a.Xo >> 1;
+  tA.assign((size_t)ntp * RK * q4, -1);
+  tO.assign((size_t)ntp * 128, -1);
+  for (int tz = 0; tz < a.ntz; ++tz)
+    for (int ty = 0; ty < a.nty; ++ty)
+      for (int tx = 0; tx < a.ntx; ++tx) {
+        const int p = (tz * a.nty + ty) * a.ntx + tx;
+        const int py0 = std::min(ty * PY, pyt - PY), px0 = std::min(tx * PX, pxt - PX);
+        const int z0 = tz * BZ, y0 = 2 * py0, x0 = 2 * px0;
+        for (int k = 0; k < RK; ++k)
+          for (int j = 0; j < q4; ++j) {
+            const int v = j + q4 * k;
+            if (v >= RV) continue;
+            const int vz = v / (RYH * RXH), rem = v - vz * (RYH * RXH), vy = rem / RXH, vx = rem - vy * RXH;
+            const int cz = z0 - 1 + vz, cy = y0 - 1 + vy, cx = x0 - 1 + vx;
+            if (cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs)
+              tA[((size_t)p * RK + k) * q4 + j] = (cz * a.Ys + cy) * a.Xs + cx;
+          }
+        for (int ab = 0; ab < 4; ++ab)
+          for (int row = 0; row < 32; ++row) {
+            const int zr = row / NP, pr = row % NP, py = pr / PX, px = pr % PX;
+            const int oz = z0 + zr, oy = y0 + 2 * py + (ab >> 1), ox = x0 + 2 * px + (ab & 1);
+            const bool own = row < ROWS && py0 + py >= ty * PY && px0 + px >= tx * PX;
+            if (own && oz < a.Zo && oy < a.Yo && ox < a.Xo) tO[(size_t)p * 128 + ab * 32 + row] = (oz * a.Yo + oy) * a.Xo + ox;
+          }
+      }
 }
 
 // instantiated tiles (bz planes, by / 2 x bx / 2 patches): full resolution 8 x 2 x 2 (32 rows), half resolution of the
@@ -500,15 +897,59 @@ bool conv_wino_ok(const ConvArgs &a) {
          a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo && conv_wino_lds(a.bz, a.by, a.bx, false, conv_wino_nbw(a.bz, a.Co)) <= (conv_wino_nbw(a.bz, a.Co) == 2 ? 160 : 80) * 1024;
 }
 
+size_t conv_wino_p_lds(int bz, int by, int bx, bool f16, int nbw) {
+  const size_t ur = (size_t)(bz + 2) * (by / 2) * (bx / 2);
+  const size_t u = 16 * ur * (f16 ? 12 : (by * bx == 16 ? 16 : 20));
+  const size_t x = (size_t)nbw * 4 * 2 * 16 * 64;
+  const size_t rimg = (size_t)(bz + 2) * (by + 2) * (bx + 2) * (bz == 8 ? 24 : 20);
+  return (128 + std::max(u, x) + rimg) * sizeof(float);       // R behind max(U, exchange): see conv_wino_p_kernel
+}
+
+// device copies of the geometry tables, one per (device, grid, tile, threads): tiny (tens of KB), built on first use
+struct WinoTabs { int *tA = nullptr, *tO = nullptr; };
+static hipError_t wino_tabs_get(const ConvArgs &a, int nth, WinoTabs *out) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int, int, int, int, int, int>, WinoTabs> cache;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const auto key = std::make_tuple(dev, a.Zo, a.Yo, a.Xo, a.bz, a.by, a.bx, nth);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    std::vector<int> tA, tO;
+    wino_tables(a, nth, tA, tO);
+    WinoTabs t;
+    hipError_t e = hipMalloc((void **)&t.tA, tA.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&t.tO, tO.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(t.tA, tA.data(), tA.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t.tO, tO.data(), tO.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    it = cache.emplace(key, t).first;
+  }
+  *out = it->second;
+  return hipSuccess;
+}
+
+static int wino_cu_count() {
+  static int cus[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int &c = cus[dev & 63];
+  if (!c) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    c = v;
+  }
+  return c;
+}
+
 hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
   ConvArgs a = a_in;
   a.dbg = conv_dbg_flags();
   if (!conv_wino_ok(a)) return hipErrorInvalidValue;
   const int nbw = conv_wino_nbw(a.bz, a.Co);
-  const dim3 grid((unsigned)(a.B * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + 31) / 32 / nbw));
-  const size_t lds = conv_wino_lds(a.bz, a.by, a.bx, f16, nbw);
-#define CM_WINO_GO(KERNEL, THREADS)                                                                 \
-  {                                                                                                 \
+  static const bool no_p = cm::diag_env("CM_NO_WINO_P") != nullptr;
+#define CM_WINO_ATTR(KERNEL)                                                                        \
     static bool attr_set[64] = {false};                                                             \
     int dev = 0;                                                                                    \
     (void)hipGetDevice(&dev);                                                                       \
@@ -516,7 +957,52 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       if (e != hipSuccess) return e;                                                                \
       attr_set[dev & 63] = true;                                                                    \
-    }                                                                                               \
+    }
+  // ---- persistent two-step form: workgroup = (tile position, sample lane), loops over its samples -----------------
+  // Measured (round 3, ATC B = 64): on the one-round launches of the two-tile form (one workgroup per sample and tile) the
+  // leaner prologue / epilogue is worth 1-2 %; on the full-resolution 8x2x2 tile (3.4 rounds) the persistent loop is no
+  // faster per tile than the hardware's own workgroup scheduling -- the kernel is issue-bound, not latency-bound: SQ counters
+  // show the SIMD 83 % busy (58 % matrix, 24 % other vector instructions) while two workgroups are resident -- and its static
+  // sample lanes balance worse (85 vs 79 us).  CM_WINO_P=1 under CM_DIAG forces it everywhere for A/B runs.
+  static const bool all_p = cm::diag_env("CM_WINO_P") != nullptr;
+  if (conv_wino_two_step(a.bz, a.by, a.bx, f16, nbw) && !no_p && (nbw == 2 || all_p)) {
+    const size_t ldsp = conv_wino_p_lds(a.bz, a.by, a.bx, f16, nbw);
+    const int ntp = a.ntz * a.nty * a.ntx, nz = (a.Co + 31) / 32 / nbw;
+    const int per_cu = (nbw == 1 && 2 * ldsp <= 160 * 1024) ? 2 : 1;
+    const int slots = wino_cu_count() * per_cu;
+    const int G = std::max(1, std::min(a.B, slots / std::max(1, ntp * nz)));
+    WinoTabs tb;
+    hipError_t et = wino_tabs_get(a, 256 * nbw, &tb);
+    if (et != hipSuccess) return et;
+    const dim3 gridp((unsigned)G, (unsigned)ntp, (unsigned)nz);
+#define CM_WINO_PGO1(KERNEL, THREADS)                                                               \
+  {                                                                                                 \
+    CM_WINO_ATTR(KERNEL)                                                                            \
+    hipLaunchKernelGGL(KERNEL, gridp, dim3(THREADS), ldsp, st, a, tb.tA, tb.tO, G);                 \
+    return hipGetLastError();                                                                       \
+  }
+#define CM_WINO_PGO(Z, PY_, PX_, F, NB, THREADS)                                                    \
+  {                                                                                                 \
+    if (a.s2w) CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, F, NB, true>), THREADS)                \
+    CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, F, NB, false>), THREADS)                          \
+  }
+#define X(z, py, px)                                                                                \
+    if (a.bz == z && a.by == 2 * py && a.bx == 2 * px && ldsp <= 160 * 1024) {                      \
+      if constexpr (z != 8) {                                                                       \
+        if (nbw == 2 && f16) CM_WINO_PGO(z, py, px, true, 2, 512)                                   \
+        if (nbw == 2) CM_WINO_PGO(z, py, px, false, 2, 512)                                         \
+      }                                                                                             \
+      if (f16) CM_WINO_PGO(z, py, px, true, 1, 256)                                                 \
+      if constexpr (z == 8 && py == 2 && px == 2) CM_WINO_PGO(z, py, px, false, 1, 256)             \
+    }
+    CM_WINO_TILES(X)
+#undef X
+  }
+  const dim3 grid((unsigned)(a.B * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + 31) / 32 / nbw));
+  const size_t lds = conv_wino_lds(a.bz, a.by, a.bx, f16, nbw);
+#define CM_WINO_GO(KERNEL, THREADS)                                                                 \
+  {                                                                                                 \
+    CM_WINO_ATTR(KERNEL)                                                                            \
     hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS), lds, st, a);                                    \
     return hipGetLastError();                                                                       \
   }

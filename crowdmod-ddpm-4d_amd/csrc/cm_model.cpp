@@ -14,6 +14,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/crowdmod_hip.h"
@@ -186,9 +187,7 @@ struct cm_model {
   bool train_fwd = false;
   // run_ops -> run_conv / fused attention: the GroupNorm finalisation op that follows a K-split layer and can ride in
   // its second pass (cm::launch_combine_gn); `fin_done` reports that it did
-  const struct Op *fin_next = nullptr;
-  int fin_b0 = 0;
-  bool fin_done = false;
+  // (the hand-off itself lives in thread-local variables, tl_fin_*: batch lanes enqueue from their own host threads)
   // training step: time-embedding projections of the batch computed from the live weights
   float *train_temb = nullptr;  // [B][nproj], row b
   long long *train_iota = nullptr;
@@ -1056,6 +1055,10 @@ int build_time_table(cm_model *m) {
 // ------------------------------------------------------------------------------
 // One convolution op of the plan for the `B` samples starting at `b0` (see run_ops).
 int run_combine(cm_model *m, cm::CombineArgs &cb, hipStream_t st);
+struct Op;
+static thread_local const Op *tl_fin_next = nullptr;   // GroupNorm finalisation waiting to ride on the next K-split second pass
+static thread_local int tl_fin_b0 = 0;
+static thread_local bool tl_fin_done = false;
 
 int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   if (op.skip_if_fused && !m->train_fwd) return 0;  // absorbed by the block's conv_2 (inference plan)
@@ -1177,14 +1180,14 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
 }
 
 // Second pass of a K-split layer (or the head sum of the fused attention block): with the consumer's GroupNorm
-// finalisation fused when run_ops found one waiting (m->fin_next) and the shapes allow it.
+// finalisation fused when run_ops found one waiting (tl_fin_next) and the shapes allow it.
 int run_combine(cm_model *m, cm::CombineArgs &cb, hipStream_t st) {
   static const bool no_fuse = cm::diag_env("CM_NO_FUSE_GNFIN") != nullptr;
-  const Op *f = m->fin_next;
-  m->fin_done = false;
+  const Op *f = tl_fin_next;
+  tl_fin_done = false;
   if (f && !no_fuse && (!f->g1 || f->g1->V() == cb.V)) {
     const Act *g1 = f->g1;
-    const int b0 = m->fin_b0, Ct = cb.C + (g1 ? g1->C : 0);
+    const int b0 = tl_fin_b0, Ct = cb.C + (g1 ? g1->C : 0);
     cb.fin_gamma = f->gamma; cb.fin_beta = f->beta;
     cb.fin_gn = f->gn_out + (size_t)b0 * 2 * Ct;
     cb.fin_mr = f->gn_mr ? f->gn_mr + (size_t)b0 * 2 * Ct : nullptr;
@@ -1194,7 +1197,7 @@ int run_combine(cm_model *m, cm::CombineArgs &cb, hipStream_t st) {
     cb.fin_groups = GN_GROUPS; cb.fin_eps = GN_EPS;
     if (cm::combine_gn_ok(cb)) {
       CM_HIP(cm::launch_combine_gn(cb, st));
-      m->fin_done = true;
+      tl_fin_done = true;
       return 0;
     }
   }
@@ -1217,13 +1220,13 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
       CM_HIP(hipEventRecord(e0, st));
     }
     // a K-split layer's second pass can carry the GroupNorm finalisation of the op that consumes its output
-    m->fin_next = nullptr; m->fin_done = false;
+    tl_fin_next = nullptr; tl_fin_done = false;
     size_t fin_at = 0;
     if ((op.kind == OP_CONV && op.ks > 1) || op.kind == OP_ATTNBLK) {
       const Act *produced = op.kind == OP_CONV ? op.out_act : op.ab_out;
       size_t j = oi + 1;
       while (j < m->ops.size() && (m->ops[j].kind == OP_ATTNBLK ? m->train_fwd : (m->ops[j].in_attn_block && !m->train_fwd))) ++j;
-      if (j < m->ops.size() && m->ops[j].kind == OP_GNFIN && m->ops[j].g0 == produced) { m->fin_next = &m->ops[j]; m->fin_b0 = b0; fin_at = j; }
+      if (j < m->ops.size() && m->ops[j].kind == OP_GNFIN && m->ops[j].g0 == produced) { tl_fin_next = &m->ops[j]; tl_fin_b0 = b0; fin_at = j; }
     }
     switch (op.kind) {
       case OP_CONV:
@@ -1281,8 +1284,8 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
       CM_HIP(hipEventRecord(m->ev_half, st));
       m->mid_at = -1;
     }
-    if (m->fin_done) oi = fin_at;   // (the ops in between are the ones this mode skips anyway)
-    m->fin_next = nullptr; m->fin_done = false;
+    if (tl_fin_done) oi = fin_at;   // (the ops in between are the ones this mode skips anyway)
+    tl_fin_next = nullptr; tl_fin_done = false;
   }
   return 0;
 }
@@ -1857,23 +1860,17 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
     hipGraphDestroy(g);
     if (ec != hipSuccess) return fail("graph replay failed: %s", hipGetErrorString(ec));
   }
-  for (size_t k = 0; !graph && k < order.size(); ++k) {
-    const int t = order[k];
-    cm::StepArgs a = base_args();
-    const cm::StepRow &r = rows[k];
-    a.step = r.step; a.c_x = r.c_x; a.c_eps = r.c_eps; a.c_noise = r.c_noise; a.draw = r.draw; a.guid = r.guid;
-    for (int ln = 0; ln < lanes; ++ln) {
-      const int b0 = off[ln], Bn = Bl[ln];
-      hipStream_t ls = sts[ln];
+  // steps [k0, k1) of batch lane `ln` on its own stream
+  auto lane_steps = [&](int ln, size_t k0, size_t k1) -> int {
+    const int b0 = off[ln], Bn = Bl[ln];
+    hipStream_t ls = sts[ln];
+    for (size_t k = k0; k < k1; ++k) {
+      const int t = order[k];
+      cm::StepArgs al = base_args();
+      const cm::StepRow &r = rows[k];
+      al.step = r.step; al.c_x = r.c_x; al.c_eps = r.c_eps; al.c_noise = r.c_noise; al.draw = r.draw; al.guid = r.guid;
       if (k == 0) CM_HIP(cm::launch_fill_t(m->tbuf + b0, Bn, t, ls));
-      // two lanes (CM_LANES=2): optionally start the second one when the first is part-way through its first step
-      static const double lane_phase = cm::diag_env("CM_LANE_PHASE") ? atof(cm::diag_env("CM_LANE_PHASE")) : 0.0;   // measured: no offset is best (1.909 ms vs 1.916 / 1.920 / 1.941 at 0.3 / 0.5 / 0.7)
-      if (k == 0 && lanes == 2 && lane_phase > 0) {
-        if (ln == 0) m->mid_at = (int)(lane_phase * (double)m->ops.size());
-        else CM_HIP(hipStreamWaitEvent(ls, m->ev_half, 0));
-      }
       if (run_ops(m, Bn, ls, b0, ln)) return 1;
-      cm::StepArgs al = a;
       al.B = Bn;
       if (k + 1 < order.size()) { al.t_next = m->tbuf + b0; al.t_next_v = order[k + 1]; }
       al.x = m->xstate + (size_t)b0 * per;
@@ -1881,9 +1878,33 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
       al.x8 = m->x8 + (size_t)b0 * m->L() * c.rows * c.cols * 8;
       al.sample_id_base = opts->sample_id_base + b0;
       al.hist = d_history ? d_history + (k + 1) * B * per + (size_t)b0 * per : nullptr;
-      al.noise = (d_noise && a.draw) ? d_noise + k * B * per + (size_t)b0 * per : nullptr;
+      al.noise = (d_noise && al.draw) ? d_noise + k * B * per + (size_t)b0 * per : nullptr;
       CM_HIP(cm::launch_sampler_step(al, ls));
     }
+    return 0;
+  };
+  if (!graph && lanes == 1) {
+    if (lane_steps(0, 0, order.size())) return 1;
+  } else if (!graph) {
+    // Step 0 of every lane from the calling thread (lazy tile set-up and function attributes happen there, once);
+    // the remaining steps of lane ln > 0 are enqueued by a host thread of its own, so that the lanes' launch
+    // streams fill independently (one thread alternating between the streams is launch-bandwidth bound).
+    for (int ln = 0; ln < lanes; ++ln)
+      if (lane_steps(ln, 0, 1)) return 1;
+    std::vector<int> rcs((size_t)lanes, 0);
+    std::vector<std::string> errs((size_t)lanes);
+    std::vector<std::thread> workers;
+    for (int ln = 1; ln < lanes; ++ln)
+      workers.emplace_back([&, ln]() {
+        if (hipSetDevice(m->device) != hipSuccess) { rcs[ln] = 1; errs[ln] = "hipSetDevice failed in a lane thread"; return; }
+        rcs[ln] = lane_steps(ln, 1, order.size());
+        if (rcs[ln]) errs[ln] = g_err;
+      });
+    rcs[0] = lane_steps(0, 1, order.size());
+    if (rcs[0]) errs[0] = g_err;
+    for (auto &w : workers) w.join();
+    for (int ln = 0; ln < lanes; ++ln)
+      if (rcs[ln]) return fail("lane %d: %s", ln, errs[ln].c_str());
   }
   for (int ln = 1; ln < lanes; ++ln) {
     CM_HIP(hipEventRecord(m->ev_join[ln], sts[ln]));

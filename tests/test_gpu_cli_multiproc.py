@@ -207,3 +207,24 @@ def test_two_stream_lanes_equal_the_single_lane_loop(tmp_path):
         assert join_all([p], 600) == [0]
         outs.append(np.load(out))
     assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+
+
+def test_bench_py_launches_its_own_ranks_and_prints_one_line():
+    """Round-2 verdict: `python bench.py --gpus N` (the form the driver uses) must start its N ranks itself.  Rehearsed
+    on the one GPU with the gloo backend (CM_BENCH_BACKEND / CM_BENCH_SHARE_GPU): the parent never touches the GPU,
+    spawns torch.distributed.run as a child, relays rank 0's single JSON line and the exit code."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CM_BENCH_BACKEND="gloo", CM_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--repeats", "1", "--batch", "4", "--cpu-budget", "0"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["value"] > 0 and j["scaling"] == "weak"
+    assert "aggregate over 2 GPUs" in j["unit"] and j["config"]["global_batch"] == 8
+    assert j["roofline"]["frac"] == pytest.approx(j["roofline"]["achieved"] / j["roofline"]["peak"])
+    assert j["roofline"]["frac"] < 1.0 and "algorithmic_frac" in j["roofline"]

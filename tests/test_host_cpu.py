@@ -505,3 +505,24 @@ def test_host_side_under_address_sanitizer():
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_self_launch_builds_a_torchrun_child_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts N ranks as a CHILD process tree (never an exec of a
+    process that touched the GPU) with the rendezvous on 127.0.0.1 and forwards its own flags."""
+    import subprocess
+    import types
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5"])
+    assert bench.self_launch(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "5"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

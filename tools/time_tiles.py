@@ -29,7 +29,9 @@ for spec_s in sys.argv[1:]:
         f = buf.value.decode().split()
         if f[0] != "conv" or key not in f[1]:
             continue
-        native.check(L.cm_debug_time_conv(h, i, 0, 0, 0, 0, B, 10, C.byref(us)))
+        if L.cm_debug_time_conv(h, i, 0, 0, 0, 0, B, 10, C.byref(us)) != 0:
+            print(f"{f[1]:44s} not timed: " + L.cm_last_error().decode())
+            continue
         base = us.value
         rc = L.cm_debug_time_conv(h, i, int(mb), int(bz), int(by), int(bx), B, 10, C.byref(us))
         print(f"{f[1]:44s} default MB{f[11]} {f[12]}x{f[13]}x{f[14]} {base:7.1f} us | MB{mb} {bz}x{by}x{bx} " +
