@@ -1,0 +1,364 @@
+// Whole-sample 3x3x3 convolution for the lowest UNet resolution (two z planes, <= 64 voxels per plane): the ten
+// quarter-resolution nn.Conv3d layers of the reference's encoder level 2 / bottleneck / decoder
+// (/root/reference/models/backbones/layers.py:30-43,57-75 -- GroupNorm -> SiLU -> conv, time row, residual / 1x1x1
+// skip conv -- as wired at unet.py:57-115).  Inference plan only.
+//
+// Why (round 3): this resolution is 13 % of the FLOPs and was a third of the step -- 25 dependent launches, each conv a
+// K-split launch (512 single-round workgroups that run prologue -> stage -> matrix phase -> cross-wave reduction -> store
+// in lock-step) plus a combine / GroupNorm-finalise launch.  At 54 voxels a SAMPLE is the natural tile:
+//   * one 512-thread workgroup = (sample, 32 output channels); the sample's whole activated input (both planes, 1-voxel
+//     in-plane halo, ALL input channels: <= 150 KB) is staged in LDS once;
+//   * the GroupNorm of the input is finalised INSIDE the workgroup from the producer's per-slot (mean, M2) partials --
+//     at this resolution that is 2-4 slots per channel, i.e. a 4 KB read -- so neither the K-split combine pass nor the
+//     gn_finalize launch exists any more (15 launches per step);
+//   * z-split as in cm_conv.hip: row block = voxels of ONE plane, so the z tap that would multiply the zero-padding plane
+//     is never issued (18 of 27 taps); here both planes share their A fragments: per in-plane tap (dy, dx) and 8-channel
+//     step the fragments of input plane 0 and 1 feed  out0 += A0 W(dz=1) + A1 W(dz=2),  out1 += A0 W(dz=0) + A1 W(dz=1);
+//   * K (in-plane tap x 8-channel step) is split over the 8 waves in contiguous ranges, weights stream global -> VGPR in
+//     consumption order (one 3 KB group per step, next group prefetched), the 8 partial accumulator sets are summed in
+//     wave order through LDS (16-byte accesses), then bias / time row / residual / fused 1x1x1 skip conv, channels-last
+//     store and the GroupNorm statistics of the output in the slot format (slot = row block).
+// Deterministic: fixed summation order, no atomics; a sample's result does not depend on the batch it is in.
+#include "cm_kernels.h"
+
+#include <algorithm>
+
+namespace cm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float silu_q(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// Chan et al. pairwise combination of (n, mean, M2) triples (same arithmetic as cm_misc.hip)
+__device__ __forceinline__ void chan_combine_q(float &n, float &mean, float &m2, float nb, float meanb, float m2b) {
+  if (nb == 0.f) return;
+  const float nt = n + nb;
+  const float d = meanb - mean;
+  const float f = nb * __builtin_amdgcn_rcpf(nt);
+  mean += d * f;
+  m2 += m2b + d * d * n * f;
+  n = nt;
+}
+
+// MBP = 32-row blocks per plane (1: up to 32 voxels per plane, 2: up to 64); MB = 2 MBP blocks per workgroup.
+template <int MBP, bool SKIP>
+__global__ __launch_bounds__(512, 2) void conv_qr_kernel(const QrArgs a) {
+  constexpr int MB = 2 * MBP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.x, nt = blockIdx.y;
+  const int Ci = a.C0 + a.C1, Q = Ci >> 2;
+  const int Y = a.Y, X = a.X, PV = Y * X, V = 2 * PV;
+  const int HX = X + 2, HYX = (Y + 2) * HX, HV = 2 * HYX;
+  const int S = Ci + 4;
+  // LDS: gtab [2 Ci] scale | shift, tmp [2 Ci + 32], hvinfo [HVp], red [2][MB][8][32], then A [HV][S] (later: P, the reduction buffer)
+  float *gtab = lds;
+  float *tmp = gtab + 2 * Ci;
+  int *hvinfo = reinterpret_cast<int *>(tmp + 2 * Ci + 32);
+  const int HVp = (HV + 3) & ~3;
+  float *red = reinterpret_cast<float *>(hvinfo + HVp);
+  float *A = red + 2 * MB * 8 * 32;
+
+  // ---- halo table: in-sample source voxel of halo voxel hv, or -1 (in-plane zero padding) ------------------------
+  if (tid < HV) {
+    const int pl = tid / HYX, rem = tid - pl * HYX, hy = rem / HX, hx = rem - hy * HX;
+    const bool in = hy >= 1 && hy <= Y && hx >= 1 && hx <= X;
+    hvinfo[tid] = in ? (pl * Y + (hy - 1)) * X + (hx - 1) : -1;
+  }
+  // ---- GroupNorm of the input, finalised here from the producers' slot partials (layers.py:30,41) ----------------
+  if (a.gamma) {
+    if (tid < Ci) {
+      const int c = tid;
+      const float *p, *nn;
+      int Cx, cc, ns;
+      if (c < a.C0) { p = a.part0; nn = a.cnt0; Cx = a.C0; cc = c; ns = a.ns0; } else { p = a.part1; nn = a.cnt1; Cx = a.C1; cc = c - a.C0; ns = a.ns1; }
+      float N = 0.f, M = 0.f, S2 = 0.f;
+      for (int s = 0; s < ns; ++s) {
+        const float2 q = *reinterpret_cast<const float2 *>(p + (((size_t)b * ns + s) * Cx + cc) * 2);
+        chan_combine_q(N, M, S2, nn[(size_t)b * ns + s], q.x, q.y);
+      }
+      tmp[c] = M;
+      tmp[Ci + c] = S2;
+    }
+    __syncthreads();
+    const int cg = Ci / a.groups;
+    if (tid < a.groups) {
+      float N = 0.f, M = 0.f, S2 = 0.f;
+      for (int i = 0; i < cg; ++i) chan_combine_q(N, M, S2, (float)V, tmp[tid * cg + i], tmp[Ci + tid * cg + i]);
+      tmp[2 * Ci + tid] = M;
+      tmp[2 * Ci + 16 + tid] = rsqrtf(S2 / N + a.eps);
+    }
+    __syncthreads();
+    if (tid < Ci) {
+      const int g = tid / cg;
+      const float sc = tmp[2 * Ci + 16 + g] * a.gamma[tid];
+      gtab[tid] = sc;
+      gtab[Ci + tid] = a.beta[tid] - tmp[2 * Ci + g] * sc;
+      if (a.gn_out && nt == 0) {                 // kept for consumers outside this kernel family (none in the inference plan)
+        a.gn_out[((size_t)b * 2 + 0) * Ci + tid] = sc;
+        a.gn_out[((size_t)b * 2 + 1) * Ci + tid] = gtab[Ci + tid];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- stage the whole activated input: thread = (halo voxel lane, channel quad) ---------------------------------
+  {
+    const int QP = 1 << a.qshift;                // power of two >= Q
+    const int q = tid & (QP - 1), hv0 = tid >> a.qshift, hvstep = 512 >> a.qshift;
+    const bool qok = q < Q;
+    const int c = 4 * q;
+    const bool from0 = c < a.C0;
+    const float *sp = from0 ? a.src0 + (size_t)b * V * a.C0 + c : a.src1 + (size_t)b * V * a.C1 + (c - a.C0);
+    const int Cs = from0 ? a.C0 : a.C1;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (a.gamma && qok) {
+      sc = *reinterpret_cast<const f32x4 *>(gtab + c);
+      sh = *reinterpret_cast<const f32x4 *>(gtab + Ci + c);
+    }
+    constexpr int SU = 8;
+    for (int h0 = hv0; h0 < HV; h0 += hvstep * SU) {
+      f32x4 v[SU];
+      int off[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int hv = h0 + u * hvstep;
+        off[u] = (hv < HV && qok) ? hvinfo[hv] : -1;
+        v[u] = *reinterpret_cast<const f32x4 *>(sp + (size_t)(off[u] >= 0 ? off[u] : 0) * Cs);
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int hv = h0 + u * hvstep;
+        f32x4 w = v[u];
+        if (a.gamma) {
+          w = w * sc + sh;
+          if (a.silu) { w[0] = silu_q(w[0]); w[1] = silu_q(w[1]); w[2] = silu_q(w[2]); w[3] = silu_q(w[3]); }
+        }
+        if (off[u] < 0) w = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hv < HV && qok) *reinterpret_cast<f32x4 *>(A + (size_t)hv * S + c) = w;
+      }
+    }
+  }
+  // ---- epilogue operands of this thread's output elements, requested now ------------------------------------------
+  const int n = nt * 32 + r;
+  const float bias_pre = a.bias[n];
+  const float tv_pre = a.temb ? a.temb[(size_t)a.tidx[b] * a.temb_stride + n] : 0.f;
+
+  // ---- per-lane A row bases: row block j of a plane holds the plane's voxels 32 j .. 32 j + 31 --------------------
+  int abase[MBP];
+#pragma unroll
+  for (int j = 0; j < MBP; ++j) {
+    const int v = min(j * 32 + r, PV - 1);
+    const int y = v / X, x = v - y * X;
+    abase[j] = (y * HX + x) * S + 4 * hh;        // tap (dy, dx) adds (dy HX + dx) S, input plane p adds p HYX S, step k8 adds 8 k8
+  }
+  f32x16 acc[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  const int K8 = Ci >> 3, ng = 9 * K8;
+  const int g0 = wave * ng / 8, g1 = (wave + 1) * ng / 8;
+  const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.wq) + (size_t)nt * ng * 3 * 64 + lane;
+  f32x4 bw[2][3];
+  if (g0 < g1) {
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz) bw[0][dz] = wq[((size_t)g0 * 3 + dz) * 64];
+  }
+  __syncthreads();                                // A complete
+
+  // ---- matrix phase: this wave's groups (k8, dy, dx), two at a time so that the weight ring is indexed statically ----
+  auto step = [&](int g, const f32x4 (&w3)[3]) {
+    const int k8 = g / 9, t9 = g - 9 * k8, dy = t9 / 3, dx = t9 - 3 * dy;
+    const int toff = (dy * HX + dx) * S + 8 * k8;
+    f32x4 a0[MBP], a1[MBP];
+#pragma unroll
+    for (int j = 0; j < MBP; ++j) {
+      a0[j] = *reinterpret_cast<const f32x4 *>(A + abase[j] + toff);
+      a1[j] = *reinterpret_cast<const f32x4 *>(A + abase[j] + toff + HYX * S);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int j = 0; j < MBP; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j][jj], w3[1][jj], acc[j], 0, 0, 0);              // out plane 0 <- in plane 0, dz = 1
+        acc[MBP + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j][jj], w3[0][jj], acc[MBP + j], 0, 0, 0);  // out plane 1 <- in plane 0, dz = 0
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j][jj], w3[2][jj], acc[j], 0, 0, 0);              // out plane 0 <- in plane 1, dz = 2
+        acc[MBP + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j][jj], w3[1][jj], acc[MBP + j], 0, 0, 0);  // out plane 1 <- in plane 1, dz = 1
+      }
+  };
+  for (int g = g0; g < g1; g += 2) {
+    if (g + 1 < g1) {
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) bw[1][dz] = wq[((size_t)(g + 1) * 3 + dz) * 64];
+    }
+    step(g, bw[0]);
+    if (g + 1 < g1) {
+      if (g + 2 < g1) {
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) bw[0][dz] = wq[((size_t)(g + 2) * 3 + dz) * 64];
+      }
+      step(g + 1, bw[1]);
+    }
+  }
+  // ---- fused 1x1x1 skip convolution on the RAW block input (layers.py:46,74): 8-channel steps dealt round-robin ----
+  if constexpr (SKIP) {
+    const int Cs2 = a.s2C0 + a.s2C1, ngs = Cs2 >> 3;
+    const f32x4 *ws = reinterpret_cast<const f32x4 *>(a.s2w) + (size_t)nt * ngs * 64 + lane;
+    for (int gs = wave; gs < ngs; gs += 8) {
+      const int c = 8 * gs + 4 * hh;
+      const bool s0 = c < a.s2C0;
+      const float *sp = s0 ? a.s2src0 + (size_t)b * V * a.s2C0 + c : a.s2src1 + (size_t)b * V * a.s2C1 + (c - a.s2C0);
+      const int Cs = s0 ? a.s2C0 : a.s2C1;
+      const f32x4 w4 = ws[(size_t)gs * 64];
+      f32x4 av[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const int pz = i / MBP, j = i % MBP;
+        const int v = min(j * 32 + r, PV - 1);
+        av[i] = *reinterpret_cast<const f32x4 *>(sp + (size_t)(pz * PV + v) * Cs);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][jj], w4[jj], acc[i], 0, 0, 0);
+    }
+  }
+  // ---- sum the 8 waves' partial accumulators in wave order through LDS -------------------------------------------------
+  __syncthreads();                                // every wave is done reading A: reuse it as P[8 waves][MB][4][64] float4
+  f32x4 *P = reinterpret_cast<f32x4 *>(A);
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      P[((size_t)(wave * MB + i) * 4 + q) * 64 + lane] = f32x4{acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+  __syncthreads();
+  constexpr int NPW = MB * 4 / 8;                 // (block, register quad) pairs per wave: 1 (MB = 2) or 2 (MB = 4)
+  float val[NPW][4];
+  int oidx[NPW][4];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int pi = wave * NPW + i, mb = pi >> 2, q = pi & 3;
+    f32x4 s = P[((size_t)(0 * MB + mb) * 4 + q) * 64 + lane];
+#pragma unroll
+    for (int ws2 = 1; ws2 < 8; ++ws2) s += P[((size_t)(ws2 * MB + mb) * 4 + q) * 64 + lane];
+    const int pz = mb / MBP, j = mb % MBP;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int v = j * 32 + 8 * q + 4 * hh + e;   // accumulator register 4 q + e of lane half hh: row 8 q + 4 hh + e of the block
+      oidx[i][e] = v < PV ? pz * PV + v : -1;
+      val[i][e] = s[e] + bias_pre + tv_pre;
+    }
+  }
+  if (a.resid) {
+    const float *rp = a.resid + (size_t)b * V * a.res_cs + n;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[i][e] += rp[(size_t)(oidx[i][e] >= 0 ? oidx[i][e] : 0) * a.res_cs];
+  }
+  {
+    float *op = a.out + (size_t)b * V * a.out_cs + n;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (oidx[i][e] >= 0) op[(size_t)oidx[i][e] * a.out_cs] = val[i][e];
+  }
+  // ---- GroupNorm statistics of the output: per (slot = row block, channel) mean and M2 over the block's valid rows ----
+  if (a.stat_part) {
+    float *red1 = red, *red2 = red + MB * 8 * 32;   // [MB][8 = (q, hh)][32 channels]
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int pi = wave * NPW + i, mb = pi >> 2, q = pi & 3;
+      float s1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (oidx[i][e] >= 0) s1 += val[i][e];
+      red1[(mb * 8 + 2 * q + hh) * 32 + r] = s1;
+    }
+    __syncthreads();
+    float mean[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int pi = wave * NPW + i, mb = pi >> 2, q = pi & 3, j = mb % MBP;
+      const float cnt = (float)max(0, min(32, PV - 32 * j));
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red1[(mb * 8 + k) * 32 + r];
+      mean[i] = cnt > 0.f ? t / cnt : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (oidx[i][e] >= 0) { const float d = val[i][e] - mean[i]; m2 += d * d; }
+      red2[(mb * 8 + 2 * q + hh) * 32 + r] = m2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int pi = wave * NPW + i, mb = pi >> 2, q = pi & 3, j = mb % MBP;
+      if (q == 0 && hh == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red2[(mb * 8 + k) * 32 + r];
+        float *sp2 = a.stat_part + (((size_t)b * MB + mb) * a.stat_C + n) * 2;
+        sp2[0] = mean[i];
+        sp2[1] = t;
+        if (r == 0 && nt == 0) a.stat_cnt[(size_t)b * MB + mb] = (float)max(0, min(32, PV - 32 * j));
+      }
+    }
+  }
+}
+
+size_t conv_qr_lds(const QrArgs &a, int MBP) {
+  const int Ci = a.C0 + a.C1, HV = 2 * (a.Y + 2) * (a.X + 2), MB = 2 * MBP;
+  const size_t head = (size_t)2 * Ci + 2 * Ci + 32 + ((HV + 3) & ~3) + 2 * MB * 8 * 32;
+  const size_t amat = (size_t)HV * (Ci + 4), pbuf = (size_t)8 * MB * 4 * 64 * 4;
+  return (head + std::max(amat, pbuf)) * sizeof(float);
+}
+
+bool conv_qr_ok(const QrArgs &a) {
+  const int Ci = a.C0 + a.C1, PV = a.Y * a.X;
+  if (PV < 1 || PV > 64 || Ci % 8 || a.C0 % 4 || a.C1 % 4 || Ci > 512 || a.Co % 32 || a.groups > 16 || (a.gamma && Ci % a.groups)) return false;
+  if (a.s2w && ((a.s2C0 + a.s2C1) % 8 || a.s2C0 % 4 || a.s2C1 % 4)) return false;
+  if (2 * (a.Y + 2) * (a.X + 2) > 512) return false;
+  return conv_qr_lds(a, PV > 32 ? 2 : 1) <= 160 * 1024;
+}
+
+hipError_t launch_conv_qr(const QrArgs &a_in, hipStream_t st) {
+  QrArgs a = a_in;
+  if (!conv_qr_ok(a)) return hipErrorInvalidValue;
+  const int Q = (a.C0 + a.C1) >> 2;
+  a.qshift = 0;
+  while ((1 << a.qshift) < Q) ++a.qshift;
+  if (a.qshift > 9) return hipErrorInvalidValue;
+  const int MBP = a.Y * a.X > 32 ? 2 : 1;
+  const size_t lds = conv_qr_lds(a, MBP);
+  const dim3 grid((unsigned)a.B, (unsigned)(a.Co / 32));
+#define CM_QR_GO(KERNEL)                                                                            \
+  {                                                                                                 \
+    static bool attr_set[64] = {false};                                                             \
+    int dev = 0;                                                                                    \
+    (void)hipGetDevice(&dev);                                                                       \
+    if (!attr_set[dev & 63]) {                                                                      \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (e != hipSuccess) return e;                                                                \
+      attr_set[dev & 63] = true;                                                                    \
+    }                                                                                               \
+    hipLaunchKernelGGL(KERNEL, grid, dim3(512), lds, st, a);                                        \
+    return hipGetLastError();                                                                       \
+  }
+  if (MBP == 1) {
+    if (a.s2w) CM_QR_GO((conv_qr_kernel<1, true>))
+    CM_QR_GO((conv_qr_kernel<1, false>))
+  }
+  if (a.s2w) CM_QR_GO((conv_qr_kernel<2, true>))
+  CM_QR_GO((conv_qr_kernel<2, false>))
+#undef CM_QR_GO
+}
+
+}  // namespace cm

@@ -124,6 +124,40 @@ hipError_t launch_wgrad_wino_reduce(const float *part, int G, int ncb, int nkb, 
 // tile (bz, by, bx) the Winograd kernel would use for an output grid, or false if none of its shapes fits
 bool conv_wino_pick(int Zo, int Yo, int Xo, int *bz, int *by, int *bx);
 
+// Whole-sample 3x3x3 convolution of the lowest resolution (cm_conv_qr.hip): two z planes, <= 64 voxels per plane; one
+// 512-thread workgroup = (sample, 32 output channels).  The GroupNorm of the input is finalised inside the kernel from the
+// producers' per-slot (mean, M2) partials; the output's statistics are written in the same slot format (2 or 4 slots).
+struct QrArgs {
+  const float *src0, *src1;      // channels-last [B][2][Y][X][C0 / C1] (torch.cat dim=1 of the two)
+  int C0, C1;
+  const float *part0, *cnt0;     // slot partials of src0: part [B][ns0][C0][2] (mean, M2), cnt [B][ns0]
+  int ns0;
+  const float *part1, *cnt1;
+  int ns1;
+  const float *gamma, *beta;     // affine of this layer's GroupNorm over the C0 + C1 channels (null: no normalisation)
+  int groups;
+  float eps;
+  int silu;
+  float *gn_out;                 // optional [B][2][C0 + C1] copy of the folded scale / shift rows
+  const float *wq;               // [Co / 32][g = k8 * 9 + dy * 3 + dx][dz][64 lanes][4]: W[co = 32 nt + lane % 32][ci = 8 k8 + 4 (lane / 32) + jj][(dz, dy, dx)]
+  const float *bias;
+  const float *temb;
+  int temb_stride;
+  const long long *tidx;
+  const float *resid;
+  int res_cs;
+  float *out;
+  int out_cs, Co, B, Y, X;
+  float *stat_part, *stat_cnt;   // output statistics: part [B][2 MBP][stat_C][2], cnt [B][2 MBP]; MBP = 1 (Y X <= 32) or 2
+  int stat_C;
+  const float *s2src0, *s2src1;  // fused 1x1x1 skip conv on the RAW block input (null s2w: none)
+  int s2C0, s2C1;
+  const float *s2w;              // [Co / 32][Cs / 8][64 lanes][4]
+  int qshift;                    // (set by the launcher) log2 of the staging's channel-quad lane count
+};
+bool conv_qr_ok(const QrArgs &a);
+hipError_t launch_conv_qr(const QrArgs &a, hipStream_t st);
+
 // ---- small kernels --------------------------------------------------------
 // Per-(sample, slice, channel) mean and M2 of a channels-last tensor.
 //   part [B][nslice][C][2]

@@ -109,6 +109,9 @@ struct Op {
   float *d_wwino16 = nullptr;   // the same weights as f16 operands (reduced-precision plan, cm_model_set_precision)
   float *d_wfrag16 = nullptr;   // f16 fragments of a parity-form upsample conv (reduced-precision plan)
   long long wpar_stride16 = 0;
+  bool qr = false;          // whole-sample kernel of the lowest resolution (cm_conv_qr.hip), inference plan
+  float *d_wqr = nullptr, *d_wqr_skip = nullptr;
+  bool qr_consumer = false; // OP_GNFIN whose only consumer is a qr conv: that kernel finalises the statistics itself
   bool first_k = false;     // the UNet's first conv on its dedicated kernel (cm_conv_io.hip)
   int first_cin = 4;        //   input channels it contracts per tap: 4 (C <= 4) or 8
   float *d_wfirst = nullptr;
@@ -647,6 +650,36 @@ struct ConvSpec {
   std::string skip_w, skip_b;
 };
 
+// Weights of the whole-sample quarter-resolution kernel (cm_conv_qr.hip): [Co/32][g = k8*9 + dy*3 + dx][dz][lane][jj]
+// with co = 32 nt + lane % 32, ci = 8 k8 + 4 (lane / 32) + jj; `wi` in the internal tap order [Co][Ci][(dz*3 + dy)*3 + dx].
+std::vector<float> pack_qr(const std::vector<float> &wi, int Co, int Ci) {
+  const int ntn = Co / 32, K8 = Ci / 8, ng = 9 * K8;
+  std::vector<float> out((size_t)ntn * ng * 3 * 64 * 4, 0.f);
+  size_t o = 0;
+  for (int nt = 0; nt < ntn; ++nt)
+    for (int g = 0; g < ng; ++g)
+      for (int dz = 0; dz < 3; ++dz)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int jj = 0; jj < 4; ++jj, ++o) {
+            const int k8 = g / 9, t9 = g % 9, dy = t9 / 3, dx = t9 % 3;
+            const int co = nt * 32 + (lane & 31), ci = 8 * k8 + 4 * (lane >> 5) + jj;
+            out[o] = wi[((size_t)co * Ci + ci) * 27 + (dz * 3 + dy) * 3 + dx];
+          }
+  return out;
+}
+// its fused 1x1x1 skip weights: [Co/32][Cs/8][lane][jj]; `w2` is [Co][Cs]
+std::vector<float> pack_qr_skip(const float *w2, int Co, int Cs) {
+  const int ntn = Co / 32, ngs = Cs / 8;
+  std::vector<float> out((size_t)ntn * ngs * 64 * 4, 0.f);
+  size_t o = 0;
+  for (int nt = 0; nt < ntn; ++nt)
+    for (int gs = 0; gs < ngs; ++gs)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int jj = 0; jj < 4; ++jj, ++o)
+          out[o] = w2[(size_t)(nt * 32 + (lane & 31)) * Cs + 8 * gs + 4 * (lane >> 5) + jj];
+  return out;
+}
+
 int add_conv(cm_model *m, const ConvSpec &s) {
   Op op;
   op.kind = OP_CONV;
@@ -807,6 +840,24 @@ int add_conv(cm_model *m, const ConvSpec &s) {
       for (int i = 0; i < s.Co; ++i) bf[i] = b.host[i] + b2.host[i];
       if (upload(m, bf, &op.d_bias_fused)) return 1;
       op.skip0 = s.skip0; op.skip1 = s.skip1; op.skip_w = s.skip_w; op.skip_b = s.skip_b;
+    }
+  }
+  // Lowest resolution (two z planes, <= 64 voxels per plane): whole-sample kernel with the GroupNorm finalisation of its
+  // input inside (cm_conv_qr.hip), inference plan.  The K-split / generic set-up above stays for the training forward.
+  if (s.ntaps == 27 && !parity && s.stride == 1 && !s.ups && s.gn && op.gn_op >= 0 && s.ci_valid < 0 && s.out->Z == 2 && s.s0->Z == 2 &&
+      s.out->Y * s.out->X <= 64 && s.Co % 32 == 0 && s.Co == s.out->C && op.stat_act && (!s.skip0 || op.d_s2w) &&
+      !cm::diag_env("CM_NO_QR")) {
+    cm::QrArgs q{};
+    q.C0 = a.C0; q.C1 = a.C1; q.Co = s.Co; q.Y = s.out->Y; q.X = s.out->X; q.groups = GN_GROUPS; q.gamma = m->ops[op.gn_op].gamma;
+    if (op.d_s2w) { q.s2w = op.d_s2w; q.s2C0 = s.skip0->C; q.s2C1 = s.skip1 ? s.skip1->C : 0; }
+    if (cm::conv_qr_ok(q)) {
+      if (upload(m, pack_qr(wi, s.Co, Ci_ref), &op.d_wqr)) return 1;
+      if (op.d_s2w) {
+        const Param &w2 = P(m, s.skip_w);
+        if (upload(m, pack_qr_skip(w2.host.data(), s.Co, (int)w2.shape[1]), &op.d_wqr_skip)) return 1;
+      }
+      op.qr = true;
+      m->ops[op.gn_op].qr_consumer = true;
     }
   }
   op.flops_per_sample = 2.0 * s.out->V() * s.Co * (double)Ci_ref * s.ntaps;
@@ -1060,8 +1111,43 @@ static thread_local const Op *tl_fin_next = nullptr;   // GroupNorm finalisation
 static thread_local int tl_fin_b0 = 0;
 static thread_local bool tl_fin_done = false;
 
+// the whole-sample kernel of the lowest resolution (inference plan): the GroupNorm statistics of its sources come raw
+int run_conv_qr(cm_model *m, Op &op, int B, hipStream_t st, int b0) {
+  const Op &gop = m->ops[op.gn_op];
+  const Act *g0 = gop.g0, *g1 = gop.g1;
+  const cm::ConvArgs &ca = op.ca;
+  const size_t V = (size_t)ca.Zo * ca.Yo * ca.Xo;
+  cm::QrArgs q{};
+  q.src0 = ca.src0 + (size_t)b0 * V * ca.C0; q.C0 = ca.C0;
+  q.src1 = ca.src1 ? ca.src1 + (size_t)b0 * V * ca.C1 : nullptr; q.C1 = ca.C1;
+  q.part0 = g0->part + (size_t)b0 * g0->nslots * g0->C * 2; q.cnt0 = g0->cnt + (size_t)b0 * g0->nslots; q.ns0 = g0->nslots;
+  if (g1) { q.part1 = g1->part + (size_t)b0 * g1->nslots * g1->C * 2; q.cnt1 = g1->cnt + (size_t)b0 * g1->nslots; q.ns1 = g1->nslots; }
+  if (g0->C != ca.C0 || (g1 ? g1->C : 0) != ca.C1) return fail("quarter-resolution conv %s: statistics and sources disagree", op.label.c_str());
+  q.gamma = gop.gamma; q.beta = gop.beta; q.groups = GN_GROUPS; q.eps = GN_EPS; q.silu = ca.silu;
+  q.wq = op.d_wqr; q.bias = ca.bias;
+  q.temb = ca.temb; q.temb_stride = ca.temb_stride; q.tidx = ca.tidx + b0;
+  q.resid = ca.resid ? ca.resid + (size_t)b0 * V * ca.res_cs : nullptr; q.res_cs = ca.res_cs;
+  if (op.d_wqr_skip) {
+    q.s2w = op.d_wqr_skip;
+    q.s2src0 = op.skip0->d + (size_t)b0 * V * op.skip0->C; q.s2C0 = op.skip0->C;
+    q.s2src1 = op.skip1 ? op.skip1->d + (size_t)b0 * V * op.skip1->C : nullptr; q.s2C1 = op.skip1 ? op.skip1->C : 0;
+    q.resid = nullptr;
+    q.bias = op.d_bias_fused;
+  }
+  q.out = ca.out + (size_t)b0 * V * ca.out_cs; q.out_cs = ca.out_cs; q.Co = ca.Co; q.B = B; q.Y = ca.Yo; q.X = ca.Xo;
+  const int ns = ca.Yo * ca.Xo > 32 ? 4 : 2;
+  q.stat_C = op.stat_act->C;
+  q.stat_part = op.stat_act->part + (size_t)b0 * ns * q.stat_C * 2;
+  q.stat_cnt = op.stat_act->cnt + (size_t)b0 * ns;
+  op.stat_act->nslots = ns;
+  op.prof_B = B;
+  CM_HIP(cm::launch_conv_qr(q, st));
+  return 0;
+}
+
 int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   if (op.skip_if_fused && !m->train_fwd) return 0;  // absorbed by the block's conv_2 (inference plan)
+  if (op.qr && !m->train_fwd) return run_conv_qr(m, op, B, st, b0);
   if (op.tuned_B < 0 && op.wino) {
     // feasibility is known only with the launch geometry: a grid the Winograd tiles do not fit falls back to the
     // direct kernel (its fragments `wfrag` are packed for every conv; NB = 1 was fixed before packing)
@@ -1226,7 +1312,7 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
       const Act *produced = op.kind == OP_CONV ? op.out_act : op.ab_out;
       size_t j = oi + 1;
       while (j < m->ops.size() && (m->ops[j].kind == OP_ATTNBLK ? m->train_fwd : (m->ops[j].in_attn_block && !m->train_fwd))) ++j;
-      if (j < m->ops.size() && m->ops[j].kind == OP_GNFIN && m->ops[j].g0 == produced) { tl_fin_next = &m->ops[j]; tl_fin_b0 = b0; fin_at = j; }
+      if (j < m->ops.size() && m->ops[j].kind == OP_GNFIN && m->ops[j].g0 == produced && !(m->ops[j].qr_consumer && !m->train_fwd)) { tl_fin_next = &m->ops[j]; tl_fin_b0 = b0; fin_at = j; }
     }
     switch (op.kind) {
       case OP_CONV:
@@ -1240,6 +1326,7 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
         break;
       }
       case OP_GNFIN: {
+        if (op.qr_consumer && !m->train_fwd) break;   // its consumer finalises the statistics itself (cm_conv_qr.hip)
         if (op.g1 && op.g1->V() != op.g0->V()) return fail("concat sources disagree on voxel count");
         const Act *g0 = op.g0, *g1 = op.g1;
         const int Ct = g0->C + (g1 ? g1->C : 0);
@@ -2135,7 +2222,10 @@ int cm_model_exec_flops(const cm_model *m, int32_t B, double flops[8]) {
     const cm::ConvArgs &a = op.ca;
     const double Ci = a.C0 + a.C1;
     double f = op.flops_per_sample;
-    if (op.wino) {
+    if (op.qr) {
+      const double rows = 2.0 * (a.Yo * a.Xo > 32 ? 2 : 1) * 32;        // whole 32-row blocks, one or two per plane
+      f = rows * a.Co * (Ci * 18.0 + (op.d_wqr_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
+    } else if (op.wino) {
       int bz = 0, by = 0, bx = 0;
       if (cm::conv_wino_pick(a.Zo, a.Yo, a.Xo, &bz, &by, &bx)) {
         const double tiles = (double)(a.Zo / bz) * ((a.Yo + by - 1) / by) * ((a.Xo + bx - 1) / bx);
