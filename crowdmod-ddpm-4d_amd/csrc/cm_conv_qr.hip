@@ -314,6 +314,295 @@ __global__ __launch_bounds__(512, 2) void conv_qr_kernel(const QrArgs a) {
   }
 }
 
+// ---- v2: eight independent wave pipelines (Ci a multiple of 64, 8 GroupNorm groups) --------------------------------------
+// v1 above runs finalise -> stage everything -> matrix phase -> reduce in lock-step over the whole chip (one workgroup per
+// CU, one round): for the 128 -> 128 layers 29 us against 15 us of matrix instructions.  With K split over the waves in
+// contiguous channel ranges, wave w only ever READS the channels [w Ci/8, (w+1) Ci/8) of the staged input -- and with the
+// reference's 8 GroupNorm groups that range is exactly GroupNorm group w.  So every wave is a pipeline of its own:
+//   finalise ITS group's statistics (lanes = the group's channels, merged redundantly by every lane through a wave-private
+//   LDS row) -> per 8-channel step: halo loads of step s + 1 in flight (registers) | 9 taps x 16 MBP matrix instructions
+//   on step s | GroupNorm + SiLU of step s + 1 -> wave-private LDS slice (double-buffered, row stride 12 floats)
+// with no workgroup barrier between the table set-up and the final reduction: LDS operations of one wave execute in order,
+// so a slice written by the wave is visible to its own later reads.  The two waves of a SIMD de-phase by themselves: one
+// stages / waits for memory while the other multiplies.
+template <int MBP, bool SKIP>
+__global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
+  constexpr int MB = 2 * MBP;
+  constexpr int SS = 12;                           // slice row stride in floats: 8 channels + 4 pad (conflict-free 16-byte reads)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.x, nt = blockIdx.y;
+  const int Ci = a.C0 + a.C1, cw = Ci >> 3;         // channels per wave = per GroupNorm group
+  const int Y = a.Y, X = a.X, PV = Y * X, V = 2 * PV;
+  const int HX = X + 2, HYX = (Y + 2) * HX, HV = 2 * HYX;
+  const int HVp = (HV + 3) & ~3;
+  // LDS: hvinfo [HVp] | gst [8 waves][2][32] | red [2][MB][8][32] | slices [8 waves][2][HVp][SS]  (later: P)
+  int *hvinfo = reinterpret_cast<int *>(lds);
+  float *gst = lds + HVp;
+  float *red = gst + 8 * 64;
+  float *slices = red + 2 * MB * 8 * 32;
+  float *sl0 = slices + (size_t)wave * 2 * HVp * SS;
+
+  if (tid < HV) {
+    const int pl = tid / HYX, rem = tid - pl * HYX, hy = rem / HX, hx = rem - hy * HX;
+    const bool in = hy >= 1 && hy <= Y && hx >= 1 && hx <= X;
+    hvinfo[tid] = in ? (pl * Y + (hy - 1)) * X + (hx - 1) : -1;
+  }
+  // ---- this wave's GroupNorm group: per-channel merge of the producers' slots (lane = channel of the group) ----------
+  const int c0w = wave * cw;
+  {
+    float M = 0.f, S2 = 0.f;
+    if (lane < cw) {
+      const int c = c0w + lane;
+      const float *p, *nn;
+      int Cx, cc, ns;
+      if (c < a.C0) { p = a.part0; nn = a.cnt0; Cx = a.C0; cc = c; ns = a.ns0; } else { p = a.part1; nn = a.cnt1; Cx = a.C1; cc = c - a.C0; ns = a.ns1; }
+      float N = 0.f;
+      for (int s = 0; s < ns; ++s) {
+        const float2 q = *reinterpret_cast<const float2 *>(p + (((size_t)b * ns + s) * Cx + cc) * 2);
+        chan_combine_q(N, M, S2, nn[(size_t)b * ns + s], q.x, q.y);
+      }
+      gst[wave * 64 + lane] = M;
+      gst[wave * 64 + 32 + lane] = S2;
+    }
+  }
+  __syncthreads();                                // hvinfo (all waves) and the wave's own gst rows
+  // every lane merges the group's channels in channel order (same chain on all lanes: no cross-lane traffic)
+  float gmean, grstd;
+  {
+    float N = 0.f, M = 0.f, S2 = 0.f;
+    for (int i = 0; i < cw; ++i) chan_combine_q(N, M, S2, (float)V, gst[wave * 64 + i], gst[wave * 64 + 32 + i]);
+    gmean = M;
+    grstd = rsqrtf(S2 / N + a.eps);
+  }
+  // ---- staging items of a step: (halo voxel, channel quad of the step's 8 channels); item = lane + 64 k --------------------
+  constexpr int NIT = 6;                           // items per lane: 2 HV / 64 <= 6 (HV <= 192: conv_qr2_ok)
+  const int nit = (2 * HV + 63) >> 6;
+  int ioff[NIT];                                     // source voxel offset (-1: padding / beyond the box)
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int it = lane + 64 * k, hv = it >> 1;
+    ioff[k] = (k < nit && hv < HV) ? hvinfo[hv] : -1;
+  }
+  const int qq = lane & 1;                          // (64 k is even: the quad of an item does not depend on k)
+  const int nsteps = cw >> 3;
+  f32x4 ld[NIT], ldg, ldb;                            // halo loads of the next step and its affine rows, in flight
+  auto issue = [&](int s) {
+    const int c = c0w + 8 * s + 4 * qq;
+    ldg = *reinterpret_cast<const f32x4 *>(a.gamma + c);
+    ldb = *reinterpret_cast<const f32x4 *>(a.beta + c);
+    const bool from0 = c < a.C0;
+    const float *sp = from0 ? a.src0 + (size_t)b * V * a.C0 + c : a.src1 + (size_t)b * V * a.C1 + (c - a.C0);
+    const int Cs = from0 ? a.C0 : a.C1;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+      if (k < nit) ld[k] = *reinterpret_cast<const f32x4 *>(sp + (size_t)(ioff[k] >= 0 ? ioff[k] : 0) * Cs);
+  };
+  auto stage = [&](int s) {
+    const f32x4 sc = ldg * grstd, sh = ldb - gmean * sc;
+    float *dst = sl0 + (size_t)(s & 1) * HVp * SS + 4 * qq;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+      if (k < nit) {
+        const int it = lane + 64 * k, hv = it >> 1;
+        f32x4 w = ld[k] * sc + sh;
+        if (a.silu) { w[0] = silu_q(w[0]); w[1] = silu_q(w[1]); w[2] = silu_q(w[2]); w[3] = silu_q(w[3]); }
+        if (ioff[k] < 0) w = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hv < HV) *reinterpret_cast<f32x4 *>(dst + (size_t)hv * SS) = w;
+      }
+  };
+  issue(0);
+  const int n = nt * 32 + r;
+  const float bias_pre = a.bias[n];
+  const float tv_pre = a.temb ? a.temb[(size_t)a.tidx[b] * a.temb_stride + n] : 0.f;
+  int abase[MBP];
+#pragma unroll
+  for (int j = 0; j < MBP; ++j) {
+    const int v = min(j * 32 + r, PV - 1);
+    const int y = v / X, x = v - y * X;
+    abase[j] = (y * HX + x) * SS + 4 * hh;
+  }
+  f32x16 acc[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  const int K8 = Ci >> 3, ng = 9 * K8;
+  const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.wq) + ((size_t)nt * ng + (size_t)wave * nsteps * 9) * 3 * 64 + lane;
+  // weight ring: RD in-plane taps deep (9 = a whole step ahead where the registers allow it); slot = tap % RD is static, a
+  // slot is refilled with the group RD taps later right after its use.  One tap ahead (1 k matrix cycles) was less than the
+  // L2 latency under load: the waves stalled on their weights at every tap (28.6 us for 15 us of matrix instructions).
+  constexpr int RD = MBP == 1 ? 9 : 3;
+  const int ngw = nsteps * 9;                      // groups of this wave
+  f32x4 bw[RD][3];
+#pragma unroll
+  for (int t = 0; t < RD; ++t)
+    if (t < ngw) {
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) bw[t][dz] = wq[((size_t)t * 3 + dz) * 64];
+    }
+  stage(0);
+  if (nsteps > 1) issue(1);
+
+  for (int s = 0; s < nsteps; ++s) {
+    const float *Asl = sl0 + (size_t)(s & 1) * HVp * SS;
+    // 9 in-plane taps of this 8-channel step; the weight ring holds the next tap (or the next step's first one)
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+      const int gl = s * 9 + t9;                    // group index within this wave's range
+      const int dy = t9 / 3, dx = t9 - 3 * dy;
+      const int toff = (dy * HX + dx) * SS;
+      f32x4 a0[MBP], a1[MBP];
+#pragma unroll
+      for (int j = 0; j < MBP; ++j) {
+        a0[j] = *reinterpret_cast<const f32x4 *>(Asl + abase[j] + toff);
+        a1[j] = *reinterpret_cast<const f32x4 *>(Asl + abase[j] + toff + HYX * SS);
+      }
+      f32x4 w3[3];
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) w3[dz] = bw[t9 % RD][dz];
+      if (gl + RD < ngw) {                          // refill this slot: its registers are free once the matrix instructions below have read them
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) bw[t9 % RD][dz] = wq[((size_t)(gl + RD) * 3 + dz) * 64];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int j = 0; j < MBP; ++j) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j][jj], w3[1][jj], acc[j], 0, 0, 0);
+          acc[MBP + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j][jj], w3[0][jj], acc[MBP + j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j][jj], w3[2][jj], acc[j], 0, 0, 0);
+          acc[MBP + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j][jj], w3[1][jj], acc[MBP + j], 0, 0, 0);
+        }
+    }
+    if (s + 1 < nsteps) {
+      stage(s + 1);
+      if (s + 2 < nsteps) issue(s + 2);
+    }
+  }
+  if constexpr (SKIP) {
+    const int Cs2 = a.s2C0 + a.s2C1, ngs = Cs2 >> 3;
+    const f32x4 *ws = reinterpret_cast<const f32x4 *>(a.s2w) + (size_t)nt * ngs * 64 + lane;
+    for (int gs = wave; gs < ngs; gs += 8) {
+      const int c = 8 * gs + 4 * hh;
+      const bool s0 = c < a.s2C0;
+      const float *sp = s0 ? a.s2src0 + (size_t)b * V * a.s2C0 + c : a.s2src1 + (size_t)b * V * a.s2C1 + (c - a.s2C0);
+      const int Cs = s0 ? a.s2C0 : a.s2C1;
+      const f32x4 w4 = ws[(size_t)gs * 64];
+      f32x4 av[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const int pz = i / MBP, j = i % MBP;
+        const int v = min(j * 32 + r, PV - 1);
+        av[i] = *reinterpret_cast<const f32x4 *>(sp + (size_t)(pz * PV + v) * Cs);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][jj], w4[jj], acc[i], 0, 0, 0);
+    }
+  }
+  // ---- sum the 8 waves' partial accumulators in wave order through LDS (as v1) ----------------------------------------
+  __syncthreads();
+  f32x4 *P = reinterpret_cast<f32x4 *>(slices);
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      P[((size_t)(wave * MB + i) * 4 + q) * 64 + lane] = f32x4{acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+  __syncthreads();
+  constexpr int NPW = MB * 4 / 8;
+  float val[NPW][4];
+  int oidx[NPW][4];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int pi = wave * NPW + i, mb = pi >> 2, q = pi & 3;
+    f32x4 s = P[((size_t)(0 * MB + mb) * 4 + q) * 64 + lane];
+#pragma unroll
+    for (int ws2 = 1; ws2 < 8; ++ws2) s += P[((size_t)(ws2 * MB + mb) * 4 + q) * 64 + lane];
+    const int pz = mb / MBP, j = mb % MBP;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int v = j * 32 + 8 * q + 4 * hh + e;
+      oidx[i][e] = v < PV ? pz * PV + v : -1;
+      val[i][e] = s[e] + bias_pre + tv_pre;
+    }
+  }
+  if (a.resid) {
+    const float *rp = a.resid + (size_t)b * V * a.res_cs + n;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[i][e] += rp[(size_t)(oidx[i][e] >= 0 ? oidx[i][e] : 0) * a.res_cs];
+  }
+  {
+    float *op = a.out + (size_t)b * V * a.out_cs + n;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (oidx[i][e] >= 0) op[(size_t)oidx[i][e] * a.out_cs] = val[i][e];
+  }
+  if (a.stat_part) {
+    float *red1 = red, *red2 = red + MB * 8 * 32;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int pi = wave * NPW + i, mb = pi >> 2, q = pi & 3;
+      float s1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (oidx[i][e] >= 0) s1 += val[i][e];
+      red1[(mb * 8 + 2 * q + hh) * 32 + r] = s1;
+    }
+    __syncthreads();
+    float mean[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int pi = wave * NPW + i, mb = pi >> 2, q = pi & 3, j = mb % MBP;
+      const float cnt = (float)max(0, min(32, PV - 32 * j));
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red1[(mb * 8 + k) * 32 + r];
+      mean[i] = cnt > 0.f ? t / cnt : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (oidx[i][e] >= 0) { const float d = val[i][e] - mean[i]; m2 += d * d; }
+      red2[(mb * 8 + 2 * q + hh) * 32 + r] = m2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int pi = wave * NPW + i, mb = pi >> 2, q = pi & 3, j = mb % MBP;
+      if (q == 0 && hh == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red2[(mb * 8 + k) * 32 + r];
+        float *sp2 = a.stat_part + (((size_t)b * MB + mb) * a.stat_C + n) * 2;
+        sp2[0] = mean[i];
+        sp2[1] = t;
+        if (r == 0 && nt == 0) a.stat_cnt[(size_t)b * MB + mb] = (float)max(0, min(32, PV - 32 * j));
+      }
+    }
+  }
+}
+
+size_t conv_qr2_lds(const QrArgs &a, int MBP) {
+  const int HV = 2 * (a.Y + 2) * (a.X + 2), HVp = (HV + 3) & ~3, MB = 2 * MBP;
+  const size_t head = (size_t)HVp + 8 * 64 + 2 * MB * 8 * 32;
+  const size_t sl = (size_t)8 * 2 * HVp * 12, pbuf = (size_t)8 * MB * 4 * 64 * 4;
+  return (head + std::max(sl, pbuf)) * sizeof(float);
+}
+
+// v2 applies when the K ranges of the 8 waves are the 8 GroupNorm groups in whole 8-channel steps
+bool conv_qr2_ok(const QrArgs &a) {
+  const int Ci = a.C0 + a.C1;
+  return a.gamma && a.groups == 8 && Ci % 64 == 0 && Ci / 8 <= 32 && a.C0 % 4 == 0 && a.C1 % 4 == 0 && 2 * (a.Y + 2) * (a.X + 2) <= 192 &&
+         conv_qr2_lds(a, a.Y * a.X > 32 ? 2 : 1) <= 160 * 1024;
+}
+
 size_t conv_qr_lds(const QrArgs &a, int MBP) {
   const int Ci = a.C0 + a.C1, HV = 2 * (a.Y + 2) * (a.X + 2), MB = 2 * MBP;
   const size_t head = (size_t)2 * Ci + 2 * Ci + 32 + ((HV + 3) & ~3) + 2 * MB * 8 * 32;
@@ -337,7 +626,9 @@ hipError_t launch_conv_qr(const QrArgs &a_in, hipStream_t st) {
   while ((1 << a.qshift) < Q) ++a.qshift;
   if (a.qshift > 9) return hipErrorInvalidValue;
   const int MBP = a.Y * a.X > 32 ? 2 : 1;
-  const size_t lds = conv_qr_lds(a, MBP);
+  static const bool no_v2 = cm::diag_env("CM_NO_QR2") != nullptr;
+  const bool v2 = conv_qr2_ok(a) && !no_v2;
+  const size_t lds = v2 ? conv_qr2_lds(a, MBP) : conv_qr_lds(a, MBP);
   const dim3 grid((unsigned)a.B, (unsigned)(a.Co / 32));
 #define CM_QR_GO(KERNEL)                                                                            \
   {                                                                                                 \
@@ -351,6 +642,14 @@ hipError_t launch_conv_qr(const QrArgs &a_in, hipStream_t st) {
     }                                                                                               \
     hipLaunchKernelGGL(KERNEL, grid, dim3(512), lds, st, a);                                        \
     return hipGetLastError();                                                                       \
+  }
+  if (v2) {
+    if (MBP == 1) {
+      if (a.s2w) CM_QR_GO((conv_qr2_kernel<1, true>))
+      CM_QR_GO((conv_qr2_kernel<1, false>))
+    }
+    if (a.s2w) CM_QR_GO((conv_qr2_kernel<2, true>))
+    CM_QR_GO((conv_qr2_kernel<2, false>))
   }
   if (MBP == 1) {
     if (a.s2w) CM_QR_GO((conv_qr_kernel<1, true>))
