@@ -448,25 +448,26 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
 
   for (int s = 0; s < nsteps; ++s) {
     const float *Asl = sl0 + (size_t)(s & 1) * HVp * SS;
-    // 9 in-plane taps of this 8-channel step; the weight ring holds the next tap (or the next step's first one)
+    // 9 in-plane taps of this 8-channel step; A fragments are read one tap ahead, weights RD taps ahead
+    f32x4 a0[MBP], a1[MBP], a0n[MBP], a1n[MBP];
+#pragma unroll
+    for (int j = 0; j < MBP; ++j) {
+      a0[j] = *reinterpret_cast<const f32x4 *>(Asl + abase[j]);
+      a1[j] = *reinterpret_cast<const f32x4 *>(Asl + abase[j] + HYX * SS);
+    }
 #pragma unroll
     for (int t9 = 0; t9 < 9; ++t9) {
       const int gl = s * 9 + t9;                    // group index within this wave's range
-      const int dy = t9 / 3, dx = t9 - 3 * dy;
-      const int toff = (dy * HX + dx) * SS;
-      f32x4 a0[MBP], a1[MBP];
+      if (t9 + 1 < 9) {
+        const int dy = (t9 + 1) / 3, dx = (t9 + 1) - 3 * dy;
+        const int toff = (dy * HX + dx) * SS;
 #pragma unroll
-      for (int j = 0; j < MBP; ++j) {
-        a0[j] = *reinterpret_cast<const f32x4 *>(Asl + abase[j] + toff);
-        a1[j] = *reinterpret_cast<const f32x4 *>(Asl + abase[j] + toff + HYX * SS);
+        for (int j = 0; j < MBP; ++j) {
+          a0n[j] = *reinterpret_cast<const f32x4 *>(Asl + abase[j] + toff);
+          a1n[j] = *reinterpret_cast<const f32x4 *>(Asl + abase[j] + toff + HYX * SS);
+        }
       }
-      f32x4 w3[3];
-#pragma unroll
-      for (int dz = 0; dz < 3; ++dz) w3[dz] = bw[t9 % RD][dz];
-      if (gl + RD < ngw) {                          // refill this slot: its registers are free once the matrix instructions below have read them
-#pragma unroll
-        for (int dz = 0; dz < 3; ++dz) bw[t9 % RD][dz] = wq[((size_t)(gl + RD) * 3 + dz) * 64];
-      }
+      const f32x4 (&w3)[3] = bw[t9 % RD];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -476,6 +477,15 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j][jj], w3[2][jj], acc[j], 0, 0, 0);
           acc[MBP + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j][jj], w3[1][jj], acc[MBP + j], 0, 0, 0);
         }
+      // refill this slot with the group RD taps later, AFTER the matrix instructions that read it (no register copies: a copy
+      // of the slot per tap was 12 vector moves that the fp32 matrix pipe does not hide)
+      if (gl + RD < ngw) {
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) bw[t9 % RD][dz] = wq[((size_t)(gl + RD) * 3 + dz) * 64];
+      }
+      asm volatile("" ::: "memory");                // (keeps the refill here: the compiler would sink it to its first use)
+#pragma unroll
+      for (int j = 0; j < MBP; ++j) { a0[j] = a0n[j]; a1[j] = a1n[j]; }
     }
     if (s + 1 < nsteps) {
       stage(s + 1);

@@ -158,6 +158,14 @@ struct QrArgs {
 bool conv_qr_ok(const QrArgs &a);
 hipError_t launch_conv_qr(const QrArgs &a, hipStream_t st);
 
+// Direct 3x3x3 stride-1 conv with f16 operands (cm_conv_f16.hip; reduced-precision plan): a.bz/by/bx = output box (divides the
+// grid), mbw = 32-row blocks per wave; a.wfrag: [Co/(32 NB)][Ci/16][27][NB][64 lanes][8 halves], a.s2w: [Co/(32 NB)][Cs/16][NB][64][8]
+// with NB = 2 when Co % 64 == 0 else 1; statistics slots per sample: conv_f16d_slots.
+bool conv_f16d_pick(int Z, int Y, int X, int *bz, int *by, int *bx, int *mbw);
+bool conv_f16d_ok(const ConvArgs &a, int mbw);
+int conv_f16d_slots(const ConvArgs &a, int mbw);
+hipError_t launch_conv_f16d(const ConvArgs &a, int mbw, hipStream_t st);
+
 // ---- small kernels --------------------------------------------------------
 // Per-(sample, slice, channel) mean and M2 of a channels-last tensor.
 //   part [B][nslice][C][2]

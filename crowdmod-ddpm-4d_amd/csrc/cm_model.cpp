@@ -109,6 +109,9 @@ struct Op {
   float *d_wwino16 = nullptr;   // the same weights as f16 operands (reduced-precision plan, cm_model_set_precision)
   float *d_wfrag16 = nullptr;   // f16 fragments of a parity-form upsample conv (reduced-precision plan)
   long long wpar_stride16 = 0;
+  bool f16d = false;        // reduced-precision plan: direct f16-operand kernel (cm_conv_f16.hip) instead of the Winograd one
+  int f16d_bz = 0, f16d_by = 0, f16d_bx = 0, f16d_mbw = 0;
+  float *d_w16d = nullptr, *d_w16d_skip = nullptr;
   bool qr = false;          // whole-sample kernel of the lowest resolution (cm_conv_qr.hip), inference plan
   float *d_wqr = nullptr, *d_wqr_skip = nullptr;
   bool qr_consumer = false; // OP_GNFIN whose only consumer is a qr conv: that kernel finalises the statistics itself
@@ -650,6 +653,26 @@ struct ConvSpec {
   std::string skip_w, skip_b;
 };
 
+// f16 fragments of the direct f16 kernel (cm_conv_f16.hip): [Co/(32 NB)][Ci/16][taps][NB][lane][8 halves] with
+// co = 32 NB nt + 32 nb + lane % 32, ci = 16 c + 8 (lane / 32) + j; `w` is [Co][Ci][taps] (taps = 27 internal order, or 1)
+std::vector<float> pack_f16d(const float *w, int Co, int Ci, int taps, int NB) {
+  const int ntn = Co / (32 * NB), nc = Ci / 16;
+  std::vector<uint16_t> out((size_t)ntn * nc * taps * NB * 64 * 8, 0);
+  size_t o = 0;
+  for (int nt = 0; nt < ntn; ++nt)
+    for (int c = 0; c < nc; ++c)
+      for (int t = 0; t < taps; ++t)
+        for (int nb = 0; nb < NB; ++nb)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j, ++o) {
+              const int co = nt * 32 * NB + nb * 32 + (lane & 31), ci = 16 * c + 8 * (lane >> 5) + j;
+              out[o] = f32_to_f16_bits(w[((size_t)co * Ci + ci) * taps + t]);
+            }
+  std::vector<float> packed(out.size() / 2);
+  std::memcpy(packed.data(), out.data(), out.size() * 2);
+  return packed;
+}
+
 // Weights of the whole-sample quarter-resolution kernel (cm_conv_qr.hip): [Co/32][g = k8*9 + dy*3 + dx][dz][lane][jj]
 // with co = 32 nt + lane % 32, ci = 8 k8 + 4 (lane / 32) + jj; `wi` in the internal tap order [Co][Ci][(dz*3 + dy)*3 + dx].
 std::vector<float> pack_qr(const std::vector<float> &wi, int Co, int Ci) {
@@ -778,6 +801,15 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     pack_wino(&wi, nullptr, s.Co, Ci_ref, Ci_pad, &ww, nullptr, nullptr);
     if (upload(m, ww, &op.d_wwino)) return 1;
     if (m->precision == CM_PRECISION_F16 && upload(m, pack_wino_f16(wi, s.Co, Ci_ref, Ci_pad), &op.d_wwino16)) return 1;
+    // reduced-precision plan: the direct f16 kernel replaces the Winograd one where its tiles fit (no transforms to pay for
+    // when the matrix instruction is 16x faster)
+    // (measured on the 24x72 grid, B = 32: 61 vs 70 us on the 32 -> 32 full-resolution layer, 136 vs 154 us on 96 -> 32, 72 vs 76 us
+    // at half resolution; on two-plane grids the two-tile Winograd form stays: 24 vs 47 us)
+    if (m->precision == CM_PRECISION_F16 && Ci_ref == Ci_pad && a.C0 % 16 == 0 && a.C1 % 16 == 0 && s.out->Z >= 4 && !cm::diag_env("CM_NO_F16D") &&
+        cm::conv_f16d_pick(s.out->Z, s.out->Y, s.out->X, &op.f16d_bz, &op.f16d_by, &op.f16d_bx, &op.f16d_mbw)) {
+      if (upload(m, pack_f16d(wi.data(), s.Co, Ci_ref, 27, s.Co % 64 == 0 ? 2 : 1), &op.d_w16d)) return 1;
+      op.f16d = true;
+    }
   }
   // the UNet's first conv (C <= 8 data channels -> base): dedicated kernel, whole weight set in registers
   if (s.s0 == m->x8_act && s.ntaps == 27 && s.stride == 1 && !s.ups && !s.gn && !s.temb && !s.resid && !s.s1 &&
@@ -840,6 +872,15 @@ int add_conv(cm_model *m, const ConvSpec &s) {
       for (int i = 0; i < s.Co; ++i) bf[i] = b.host[i] + b2.host[i];
       if (upload(m, bf, &op.d_bias_fused)) return 1;
       op.skip0 = s.skip0; op.skip1 = s.skip1; op.skip_w = s.skip_w; op.skip_b = s.skip_b;
+    }
+  }
+  if (op.f16d && op.d_s2w) {
+    const Param &w2 = P(m, s.skip_w);
+    const int Cs = (int)w2.shape[1];
+    if (Cs % 16 == 0 && s.skip0->C % 16 == 0 && (!s.skip1 || s.skip1->C % 16 == 0)) {
+      if (upload(m, pack_f16d(w2.host.data(), s.Co, Cs, 1, s.Co % 64 == 0 ? 2 : 1), &op.d_w16d_skip)) return 1;
+    } else {
+      op.f16d = false;
     }
   }
   // Lowest resolution (two z planes, <= 64 voxels per plane): whole-sample kernel with the GroupNorm finalisation of its
@@ -1247,6 +1288,20 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     cb.stat_cnt = op.stat_act->cnt + (size_t)b0 * cb.nslots;
     op.stat_act->nslots = cb.nslots;
     if (run_combine(m, cb, st)) return 1;
+  } else if (op.wino && op.f16d && !m->train_fwd) {
+    // reduced-precision plan: direct f16 kernel with its own tile geometry / statistics slots
+    ca.bz = op.f16d_bz; ca.by = op.f16d_by; ca.bx = op.f16d_bx;
+    ca.wfrag = op.d_w16d;
+    if (ca.s2w) ca.s2w = op.d_w16d_skip;
+    if (op.stat_act) {
+      const int ns16 = cm::conv_f16d_slots(ca, op.f16d_mbw);
+      if (ns16 > MAX_SLOTS) return fail("statistics slots %d exceed %d", ns16, MAX_SLOTS);
+      ca.stat_ns = ns16;
+      ca.stat_part = op.stat_act->part + (size_t)b0 * ns16 * ca.stat_C * 2;
+      ca.stat_cnt = op.stat_act->cnt + (size_t)b0 * ns16;
+      op.stat_act->nslots = ns16;
+    }
+    CM_HIP(cm::launch_conv_f16d(ca, op.f16d_mbw, st));
   } else if (op.wino) {
     // reduced-precision plan: f16 operands in the inference forward; the training forward stays fp32
     const bool f16 = op.d_wwino16 && !m->train_fwd;
@@ -2222,7 +2277,10 @@ int cm_model_exec_flops(const cm_model *m, int32_t B, double flops[8]) {
     const cm::ConvArgs &a = op.ca;
     const double Ci = a.C0 + a.C1;
     double f = op.flops_per_sample;
-    if (op.qr) {
+    if (op.f16d && m->precision == CM_PRECISION_F16) {
+      const double tiles = (double)(a.Zo / op.f16d_bz) * (a.Yo / op.f16d_by) * (a.Xo / op.f16d_bx);
+      f = tiles * 128.0 * op.f16d_mbw * a.Co * (Ci * 27.0 + (op.d_w16d_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
+    } else if (op.qr) {
       const double rows = 2.0 * (a.Yo * a.Xo > 32 ? 2 : 1) * 32;        // whole 32-row blocks, one or two per plane
       f = rows * a.Co * (Ci * 18.0 + (op.d_wqr_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
     } else if (op.wino) {

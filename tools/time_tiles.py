@@ -10,10 +10,12 @@ import numpy as np  # noqa: E402
 from crowdmod_ddpm_4d_amd import native, spec  # noqa: E402
 from crowdmod_ddpm_4d_amd.unet import UNet  # noqa: E402
 
-B, ch, H, W = 64, 4, 12, 36
+B, ch, H, W = int(os.environ.get("TT_B", 64)), 4, int(os.environ.get("TT_H", 12)), int(os.environ.get("TT_W", 36))
 net = UNet(input_channels=ch, output_channels=ch, num_res_blocks=1, base_channels=32, base_channels_multiples=(1, 2, 4),
            apply_attention=(False, False, True), max_batch=B)
 net.load_state_dict(spec.init_params(net.cfg, 42))
+if os.environ.get("TT_F16"):
+    net.set_precision("f16")
 rng = np.random.default_rng(0)
 net(rng.standard_normal((B, ch, H, W, 3), dtype=np.float32), np.arange(B) * 7 % 1000,
     rng.standard_normal((B, ch, H, W, 5), dtype=np.float32))
