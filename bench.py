@@ -193,11 +193,11 @@ def main():
                     "BASELINE configs[3]'s per-GPU shard; its own JSON line)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--lanes", type=int, default=1, help="batch lanes on separate HIP streams inside one rank (CM_LANES; 2 measured "
-                    "4 %% faster); the default 1 keeps one launch per layer so that the per-launch roofline figures are exact")
+    ap.add_argument("--lanes", type=int, default=2, help="batch lanes on separate HIP streams inside one rank (CM_LANES): the B "
+                    "chains run as `lanes` independent half-batches whose launches overlap (bit-identical results); 1 = one "
+                    "launch per layer")
     a = ap.parse_args()
-    if a.lanes > 1:
-        os.environ["CM_LANES"] = str(a.lanes)   # read once by the library at the first loop call
+    os.environ["CM_LANES"] = str(max(1, a.lanes))   # read once by the library at the first loop call
     if a.mode == "train":
         return run_train(a)
     steps = a.steps if a.steps is not None else 50
@@ -287,6 +287,8 @@ def main():
         ms = (C.c_float * 8)()
         cnt = (C.c_int64 * 8)()
         native.check(L.cm_profile_read(h, ms, cnt))
+        un = (C.c_float * 8)()
+        native.check(L.cm_profile_read_union(h, un))     # per class: union of its launch intervals over the batch lanes
         if os.environ.get("CM_BENCH_REPORT"):
             buf = C.create_string_buffer(1 << 16)
             native.check(L.cm_profile_report(h, buf, len(buf)))
@@ -299,7 +301,8 @@ def main():
         native.check(L.cm_model_cost(h, nb, C.byref(fl), C.byref(by)))
         conv3_flops = model.denoiser.conv3_flops(nb) * steps
         conv3_exec = model.denoiser.conv3_exec_flops(nb) * steps
-        conv_s = ms[0] / 1e3
+        lanes_eff = (a.lanes if (hi - lo) >= 8 * a.lanes else 1) if os.environ.get("CM_PROFILE_LANES") else 1
+        conv_s = un[0] / 1e3                              # (== ms[0] with one lane)
         ach = conv3_flops / conv_s / 1e12 if conv_s > 0 else 0.0
         exe = conv3_exec / conv_s / 1e12 if conv_s > 0 else 0.0
         peak = FP32_MFMA_PEAK_TFLOPS if a.dtype == "f32" else F16_MFMA_PEAK_TFLOPS
@@ -311,16 +314,22 @@ def main():
             "frac": exe / peak, "traffic": hbm_traffic(),
             "algorithmic_tflops": ach, "algorithmic_frac": ach / peak,
             "launches": int(cnt[0]), "avg_launch_us": ms[0] * 1e3 / max(1, cnt[0]),
-            "measured_with": "an extra run of the same K steps, same launch configuration, with HIP events around every "
-                             "launch on its launch stream (events inside the timed runs would add ~1.5 us per launch to "
-                             "`value`); `achieved` / `frac` count the matrix-core FLOPs actually ISSUED (Winograd, parity and "
+            "lanes": lanes_eff, "class_busy_ms": un[0], "sum_of_launch_ms": ms[0],
+            "measured_with": "an extra run of the same K steps with HIP events around every launch on its launch stream "
+                             "(events inside the timed runs would add ~1.5 us per launch to `value`), as ONE batch lane -- one "
+                             "launch per layer over the whole batch, the configuration of `python bench.py --lanes 1` and of "
+                             "profiles/round3_kernel_stats.csv -- because two lanes' launches overlap each other (no per-launch "
+                             "duration exists) and recording events from two host threads slows the profiled pass itself by "
+                             "~15 %; `value` runs the default two lanes, which is 4-5 % faster than the sum of these launches. "
+                             "(CM_PROFILE_LANES=1 profiles the lanes: class time = union of the launch intervals, "
+                             "`class_busy_ms`.)  `achieved` / `frac` count the matrix-core FLOPs actually ISSUED (Winograd, parity and "
                              "z-split forms issue fewer than the direct form) -- the hardware fraction; `algorithmic_*` counts "
                              "2 x 27 x Ci x Co per voxel as PyTorch counts the reference's nn.Conv3d and can exceed 1 (it "
                              "is the algorithmic saving, not a roof); rocprofv3 --kernel-trace --stats of this command: "
                              "profiles/round3_kernel_stats.csv",
             "executed_gflop_per_launch": conv3_exec / max(1, cnt[0]) / 1e9,
             "algorithmic_gflop_per_launch": conv3_flops / max(1, cnt[0]) / 1e9,
-            "class_ms_per_step": {k: ms[i] / steps for i, k in enumerate(
+            "class_ms_per_step": {k: un[i] / steps for i, k in enumerate(
                 ["conv3x3x3", "conv1x1x1_gemm", "groupnorm_stats", "attention_block", "elementwise"])},
             "step_algorithmic_gflop": fl.value / 1e9, "step_algorithmic_gbytes": by.value / 1e9,
         }
@@ -352,7 +361,7 @@ def main():
             "sample_steps_per_s": world * B * steps / elapsed,
             "config": {"workload": wl + ": DDPM p_sample_loop, T=%d, batch %d per GPU, UNet base 32 mult [1,2,4]" % (res.timesteps, B),
                        "channels": Cn, "grid": [res.rows, res.cols], "past_len": res.past_len,
-                       "future_len": res.future_len, "global_batch": gb, "parallelism": "batch-shard x%d" % world + (" (%d stream lanes per rank; roofline from a single-lane pass)" % a.lanes if a.lanes > 1 else "")},
+                       "future_len": res.future_len, "global_batch": gb, "parallelism": "batch-shard x%d" % world + (" (%d stream lanes of %d chains per rank)" % (a.lanes, B // a.lanes) if a.lanes > 1 and B >= 8 * a.lanes else "")},
         }
         if roofline:
             out["roofline"] = roofline

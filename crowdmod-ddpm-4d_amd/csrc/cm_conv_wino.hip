@@ -413,9 +413,16 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
     }
     // ---- matrix phase: NG groups (z tap [, 8-channel half]) x 4 components ---------------------------------
     if (a.dbg & 2) continue;
+    auto aread = [&](int g, f32x4 (&af)[4]) {
+      const int dz = F16 ? g : g >> 1, k8 = F16 ? 0 : g & 1;
+      const int acol = SWZ ? 4 * ((2 * k8 + hh) ^ (((ar >> 2) + dz) & 3)) : 8 * k8;   // swizzled 16-byte column of row ar + dz * NP
+#pragma unroll
+      for (int x = 0; x < 4; ++x) af[x] = *reinterpret_cast<const f32x4 *>(arow + (size_t)x * UR * S + (size_t)dz * NP * S + acol);
+    };
+    f32x4 afc[4], afn[4];
+    aread(0, afc);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const int dz = F16 ? g : g >> 1, k8 = F16 ? 0 : g & 1;
       // refill the other ring slot with the next group (possibly the next chunk's first)
       {
         const bool more = g < NG - 1 || ch + 1 < nchunks;
@@ -425,21 +432,21 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
           for (int x = 0; x < 4; ++x) bq[(g + 1) % RS][x] = wn[x * 64];
         }
       }
-      f32x4 af[4];
-      const int acol = SWZ ? 4 * ((2 * k8 + hh) ^ (((ar >> 2) + dz) & 3)) : 8 * k8;   // swizzled 16-byte column of row ar + dz * NP
-#pragma unroll
-      for (int x = 0; x < 4; ++x) af[x] = *reinterpret_cast<const f32x4 *>(arow + (size_t)x * UR * S + (size_t)dz * NP * S + acol);
+      if (g + 1 < NG) aread(g + 1, afn);
+      asm volatile("" ::: "memory");          // next group's weights and A fragments are REQUESTED here, not at their first use
       if constexpr (F16) {
 #pragma unroll
         for (int x = 0; x < 4; ++x)
-          acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[x]), __builtin_bit_cast(f16x8, bq[g % RS][x]), acc[x], 0, 0, 0);
+          acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afc[x]), __builtin_bit_cast(f16x8, bq[g % RS][x]), acc[x], 0, 0, 0);
       } else {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
           for (int x = 0; x < 4; ++x)
-            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x][jj], bq[g % RS][x][jj], acc[x], 0, 0, 0);
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(afc[x][jj], bq[g % RS][x][jj], acc[x], 0, 0, 0);
       }
+#pragma unroll
+      for (int x = 0; x < 4; ++x) afc[x] = afn[x];
     }
   }
 
@@ -970,7 +977,8 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
     const int ntp = a.ntz * a.nty * a.ntx, nz = (a.Co + 31) / 32 / nbw;
     const int per_cu = (nbw == 1 && 2 * ldsp <= 160 * 1024) ? 2 : 1;
     const int slots = wino_cu_count() * per_cu;
-    const int G = std::max(1, std::min(a.B, slots / std::max(1, ntp * nz)));
+    static const int g_force = cm::diag_env("CM_WINO_G") ? atoi(cm::diag_env("CM_WINO_G")) : 0;
+    const int G = g_force > 0 ? std::min(a.B, g_force) : std::max(1, std::min(a.B, slots / std::max(1, ntp * nz)));
     WinoTabs tb;
     hipError_t et = wino_tabs_get(a, 256 * nbw, &tb);
     if (et != hipSuccess) return et;

@@ -216,7 +216,9 @@ struct cm_model {
   bool profile = false;
   float prof_ms[K_NCLASS] = {0};
   int64_t prof_n[K_NCLASS] = {0};
-  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events[4];   // per batch lane (each lane's thread appends to its own)
+  hipEvent_t prof_base = nullptr;                 // time origin of a profiled call (recorded on the call's stream)
+  float prof_union_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per class: length of the UNION of its launch intervals over all lanes
 
   int L() const { return cfg.past_len + cfg.future_len; }
   int64_t per_sample() const { return (int64_t)cfg.in_channels * cfg.rows * cfg.cols * cfg.future_len; }
@@ -1420,7 +1422,7 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
     }
     if (m->profile) {
       CM_HIP(hipEventRecord(e1, st));
-      m->prof_events.push_back({(int)oi, {e0, e1}});
+      m->prof_events[slab & 3].push_back({(int)oi, {e0, e1}});
     }
     if (m->mid_at >= 0 && (int)oi >= m->mid_at) {
       CM_HIP(hipEventRecord(m->ev_half, st));
@@ -1432,28 +1434,50 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
   return 0;
 }
 
-int prof_begin(cm_model *m) {
+int prof_begin(cm_model *m, hipStream_t st) {
   if (!m->profile) return 0;
-  for (int i = 0; i < K_NCLASS; ++i) { m->prof_ms[i] = 0; m->prof_n[i] = 0; }
+  for (int i = 0; i < K_NCLASS; ++i) { m->prof_ms[i] = 0; m->prof_n[i] = 0; m->prof_union_ms[i] = 0; }
   for (Op &op : m->ops) { op.prof_ms = 0; op.prof_n = 0; }
+  if (!m->prof_base) CM_HIP(hipEventCreate(&m->prof_base));
+  CM_HIP(hipEventRecord(m->prof_base, st));
   return 0;
 }
 
+// Per-launch durations (summed per op and per class) and, per class, the length of the UNION of the launch intervals over
+// all batch lanes: with two lanes the launches of one class overlap each other and other classes, so "class time" is the
+// time during which at least one launch of the class was running (all offsets against prof_base).
 int prof_collect(cm_model *m, hipStream_t st) {
   if (!m->profile) return 0;
-  CM_HIP(hipStreamSynchronize(st));
-  for (auto &pe : m->prof_events) {
-    float ms = 0;
-    CM_HIP(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
-    Op &op = m->ops[pe.first];
-    op.prof_ms += ms;
-    op.prof_n += 1;
-    m->prof_ms[op.cls] += ms;
-    m->prof_n[op.cls] += 1;
-    hipEventDestroy(pe.second.first);
-    hipEventDestroy(pe.second.second);
+  CM_HIP(hipDeviceSynchronize());
+  (void)st;
+  std::vector<std::pair<float, float>> iv[K_NCLASS];
+  for (int ln = 0; ln < 4; ++ln) {
+    for (auto &pe : m->prof_events[ln]) {
+      float t0 = 0, t1 = 0;
+      CM_HIP(hipEventElapsedTime(&t0, m->prof_base, pe.second.first));
+      CM_HIP(hipEventElapsedTime(&t1, m->prof_base, pe.second.second));
+      const float ms = t1 - t0;
+      Op &op = m->ops[pe.first];
+      op.prof_ms += ms;
+      op.prof_n += 1;
+      m->prof_ms[op.cls] += ms;
+      m->prof_n[op.cls] += 1;
+      iv[op.cls].push_back({t0, t1});
+      hipEventDestroy(pe.second.first);
+      hipEventDestroy(pe.second.second);
+    }
+    m->prof_events[ln].clear();
   }
-  m->prof_events.clear();
+  for (int c = 0; c < K_NCLASS; ++c) {
+    std::sort(iv[c].begin(), iv[c].end());
+    float total = 0, lo = 0, hi = -1;
+    for (auto &x : iv[c]) {
+      if (hi < lo || x.first > hi) { if (hi >= lo) total += hi - lo; lo = x.first; hi = x.second; }
+      else hi = std::max(hi, x.second);
+    }
+    if (hi >= lo) total += hi - lo;
+    m->prof_union_ms[c] = total;
+  }
   return 0;
 }
 
@@ -1629,6 +1653,7 @@ int cm_model_destroy(cm_model *m) {
   }
   if (m->ev_fork) hipEventDestroy(m->ev_fork);
   if (m->ev_half) hipEventDestroy(m->ev_half);
+  if (m->prof_base) hipEventDestroy(m->prof_base);
   if (m->train) cm_free_train_state(m->train);
   delete m;
   return 0;
@@ -1714,7 +1739,7 @@ int cm_unet_forward(cm_model *m, const float *d_future, const int64_t *d_t, cons
   DevGuard g(m->device);
   hipStream_t st = stream ? (hipStream_t)stream : m->stream;
   const cm_unet_config &c = m->cfg;
-  prof_begin(m);
+  if (prof_begin(m, st)) return 1;
   CM_HIP(hipMemcpyAsync(m->tbuf, d_t, (size_t)B * sizeof(long long), hipMemcpyDeviceToDevice, st));
   CM_HIP(cm::launch_assemble_input(d_past, d_future, m->x8, B, c.in_channels, c.rows, c.cols, c.past_len, c.future_len, 3, st));
   if (run_ops(m, B, st)) return 1;
@@ -1901,7 +1926,7 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
   const cm_unet_config &c = m->cfg;
   const size_t per = (size_t)m->per_sample();
   const std::vector<int> order = visit_order(s, opts);
-  prof_begin(m);
+  if (prof_begin(m, st)) return 1;
   // x_T: injected or drawn on device (ddpm.py:211,242)
   if (d_xT) CM_HIP(hipMemcpyAsync(m->xstate, d_xT, B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
   else CM_HIP(cm::launch_randn(m->xstate, B, (long long)per, opts->seed, opts->sample_id_base, 0x7fffffff, st));
@@ -1912,15 +1937,17 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
   const int last = s->T - 1;
   float beta_t = s->tab[CM_TAB_BETA][last], sab_t = s->tab[CM_TAB_SQRT_ALPHA_BAR][last],
         s1m_t = s->tab[CM_TAB_SQRT_ONE_MINUS_ALPHA_BAR][last];
-  // Optional batch interleave (CM_LANES=2): the chains are independent, so the batch can be cut in
-  // halves that run the whole step sequence on separate streams, with bit-identical results; the
-  // ramp-up / tail of one lane's launch is filled by the other lane's workgroups.  It was worth +7 %
-  // while the small kernels were latency chains and is worth ~1.5 % now, so whole-batch launches on one
-  // stream are the default: one launch configuration for the timed run, the per-launch HIP-event
-  // figures and the rocprofv3 trace.
-  static const int want_lanes = getenv("CM_LANES") ? atoi(getenv("CM_LANES")) : 1;
+  // Batch lanes (CM_LANES, default 2): the chains are independent, so the batch is cut in halves that run the whole step
+  // sequence on separate streams, each enqueued by its own host thread, with bit-identical results; the ramp-up / tail and the
+  // launch gaps of one lane are filled by the other lane's workgroups (-4.5 % per step at B = 64).  A profiled call keeps the
+  // lanes: its per-class time is the union of the launch intervals over both lanes (prof_collect).
+  static const int want_lanes = getenv("CM_LANES") ? atoi(getenv("CM_LANES")) : 2;
   int lanes = std::max(1, std::min(4, want_lanes));
-  if (B < 8 * lanes || m->profile || stream) lanes = 1;
+  if (B < 8 * lanes || stream || opts->use_graph) lanes = 1;
+  // a profiled call runs ONE lane unless CM_PROFILE_LANES is set: two host threads recording two events per launch slow the
+  // profiled pass itself by ~15 % (measured), which would under-report every kernel class
+  static const bool prof_lanes = getenv("CM_PROFILE_LANES") != nullptr;
+  if (m->profile && !prof_lanes) lanes = 1;
   int Bl[4], off[4];
   hipStream_t sts[4] = {st, m->lane_stream[1], m->lane_stream[2], m->lane_stream[3]};
   for (int ln = 0, o = 0; ln < lanes; ++ln) {
@@ -1963,7 +1990,7 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
     a.seed = opts->seed; a.cs = 8;
     return a;
   };
-  const bool graph = opts->use_graph && !m->profile && lanes == 1 && order.size() >= 3;
+  const bool graph = opts->use_graph && !m->profile && lanes == 1 && !stream && order.size() >= 3;
   if (graph) {
     // hipGraph replay: one captured step (the kernels read their per-step scalars from a device table indexed by a
     // device counter), launched once per remaining step.  Step 0 runs eagerly: it performs the lazy tile set-up
@@ -2112,6 +2139,12 @@ int cm_profile_enable(cm_model *m, int32_t on) {
 int cm_profile_read(cm_model *m, float ms[8], int64_t launches[8]) {
   if (!m || !ms || !launches) return fail("null argument");
   for (int i = 0; i < 8; ++i) { ms[i] = m->prof_ms[i]; launches[i] = m->prof_n[i]; }
+  return 0;
+}
+
+int cm_profile_read_union(cm_model *m, float ms[8]) {
+  if (!m || !ms) return fail("null argument");
+  for (int i = 0; i < 8; ++i) ms[i] = m->prof_union_ms[i];
   return 0;
 }
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     "cm_sample_num_steps": (C.c_int, [_P, C.POINTER(cm_sample_opts), C.POINTER(C.c_int32)]),
     "cm_profile_enable": (C.c_int, [_P, C.c_int32]),
     "cm_profile_read": (C.c_int, [_P, _F, C.POINTER(C.c_int64)]),
+    "cm_profile_read_union": (C.c_int, [_P, _F]),
     "cm_profile_report": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "cm_model_cost": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cm_model_class_flops": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double)]),

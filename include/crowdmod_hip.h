@@ -198,6 +198,10 @@ int cm_sample_num_steps(const cm_schedule *s, const cm_sample_opts *opts, int32_
  * 4 elementwise (assemble/step).  `ms` and `launches` hold 8 entries. */
 int cm_profile_enable(cm_model *m, int32_t on);
 int cm_profile_read(cm_model *m, float ms[8], int64_t launches[8]);
+/* Per class: length (ms) of the UNION of its launch intervals over all batch lanes of the last profiled call -- with
+   two lanes the launches of a class overlap, so the sum of their durations in cm_profile_read exceeds the wall time
+   they occupied; with one lane the two agree. */
+int cm_profile_read_union(cm_model *m, float ms[8]);
 /* Text table of the per-launch averages behind cm_profile_read (one line per op). */
 int cm_profile_report(cm_model *m, char *buf, int64_t capacity);
 /* Algorithmic FLOPs and bytes of one forward at batch B. */

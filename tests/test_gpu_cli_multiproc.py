@@ -170,15 +170,14 @@ def test_two_data_parallel_replicas_stay_identical(tmp_path):
 
 # ---------------------------------------------------------------------------------------------------------
 def _lanes_worker(lanes, out_path):
-    if lanes > 1:
-        os.environ["CM_LANES"] = str(lanes)     # read once by the library, hence one process per setting
+    os.environ["CM_LANES"] = str(lanes)         # read once by the library, hence one process per setting (default: 2)
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from crowdmod_ddpm_4d_amd import prng, spec
     from crowdmod_ddpm_4d_amd.config import AttrDict
     from crowdmod_ddpm_4d_amd.ddpm_model import DDPM_model
     from crowdmod_ddpm_4d_amd.diffusion import DDPM
-    gb = 19                                      # uneven lanes: 10 + 9 chains
+    gb = 25                                      # uneven lanes: 13 + 12 chains, 9 + 8 + 8
     H, W = FULL_GRIDS["atc"]
     cfg = AttrDict({
         "MACROPROPS": {"ROWS": H, "COLS": W}, "DATASET": {"PAST_LEN": 5, "FUTURE_LEN": 3, "BATCH_SIZE": gb},
@@ -200,13 +199,13 @@ def test_two_stream_lanes_equal_the_single_lane_loop(tmp_path):
     chains of the single-lane loop bit for bit (batch-shard identity; the lanes share no buffer region)."""
     ctx = mp.get_context("spawn")
     outs = []
-    for lanes in (1, 2):
+    for lanes in (1, 2, 3):
         out = str(tmp_path / f"lanes{lanes}.npy")
         p = ctx.Process(target=_lanes_worker, args=(lanes, out))
         p.start()
         assert join_all([p], 600) == [0]
         outs.append(np.load(out))
-    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 def test_bench_py_launches_its_own_ranks_and_prints_one_line():
