@@ -17,6 +17,7 @@ What is captured:
   loop_grids.npz    (--only loop_grids) _generate_ddpm T=50 on the HERMES-CR-120 (28x24) and 2x ATC (24x72) grids,
                     _generate_ddim divider 50 on CR-120
   train_full_cr120.npz  (--only train_grids) full-width training step on the CR-120 grid
+  energy.npz        (--only energy) models/guidance.py compute_energy on synthetic sequences
 
 Weights and inputs are NOT stored: both sides regenerate them bit-identically
 from the integer PRNG (crowdmod-ddpm-4d_amd/prng.py, spec.init_params).
@@ -508,6 +509,20 @@ def gen_metrics(out):
     print("metrics psnr", d["PSNR"][0], "masked nan count", int(np.isnan(d["MASK_PSNR_OVER_TIME"]).sum()))
 
 
+def gen_energy(out):
+    """models/guidance.py:10-42 compute_energy (torch-only import) on synthetic [B,3,H,W,L] tensors, with the metric's
+    delta_t = delta_l = 1 (metricsGenerator.py:278-279) and the guidance default (0.5, 1.0)."""
+    from models.guidance import compute_energy
+    B, C, H, W, L = 6, 3, 12, 36, 3
+    x = prng.normal(SEED_X, "energy/x", B * C * H * W * L).reshape(B, C, H, W, L).astype(np.float32)
+    x[:, 0] = np.maximum(x[:, 0], 0.0)
+    t = torch.from_numpy(x)
+    d = {"e11": compute_energy(t, delta_t=1, delta_l=1).numpy().astype(np.float32),
+         "e_default": compute_energy(t).numpy().astype(np.float32)}
+    np.savez_compressed(os.path.join(out, "energy.npz"), **d)
+    print("energy", d["e11"][:3])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="schedule,ops,fwd,loop,train,train_full,fm,metrics")
@@ -529,6 +544,8 @@ def main():
         gen_fm(a.out)
     if "metrics" in todo:
         gen_metrics(a.out)
+    if "energy" in todo:
+        gen_energy(a.out)
     if "loop" in todo:
         gen_loop(a.out)
     if "train_grids" in todo:
