@@ -417,6 +417,12 @@ class UNet:
         native.check(native.lib().cm_model_exec_flops(self._handle, B, fl))
         return float(fl[0])
 
+    def exec_flops(self, B: int) -> float:
+        """Matrix-core FLOPs one forward executes over all kernel classes (convolutions in their reduced forms + attention)."""
+        fl = (C.c_double * 8)()
+        native.check(native.lib().cm_model_exec_flops(self._handle, B, fl))
+        return float(sum(fl))
+
     def conv3_flops(self, B: int) -> float:
         """Algorithmic FLOPs of the 3x3x3 convolutions of one forward at batch B."""
         fl = (C.c_double * 8)()
