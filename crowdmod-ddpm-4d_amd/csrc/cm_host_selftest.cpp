@@ -189,6 +189,67 @@ void test_tile_planner() {
           }
 }
 
+// round 3: packers and planners of the new kernels (whole-sample quarter-resolution kernel, direct f16 kernel)
+void test_round3_packers() {
+  std::mt19937 rng(5);
+  std::uniform_real_distribution<float> U(-1.f, 1.f);
+  for (int Co : {32, 64, 128})
+    for (int Ci : {16, 64, 192}) {
+      std::vector<float> wi((size_t)Co * Ci * 27);
+      for (auto &v : wi) v = U(rng);
+      // pack_qr: every weight appears exactly once, at the documented position
+      const std::vector<float> q = pack_qr(wi, Co, Ci);
+      EXPECT(q.size() == wi.size());
+      const int ng = 9 * (Ci / 8);
+      for (int probe = 0; probe < 200; ++probe) {
+        const int co = (int)(rng() % Co), ci = (int)(rng() % Ci), dz = (int)(rng() % 3), dy = (int)(rng() % 3), dx = (int)(rng() % 3);
+        const int nt = co / 32, g = (ci / 8) * 9 + dy * 3 + dx, lane = 32 * ((ci % 8) / 4) + co % 32, jj = ci % 4;
+        EXPECT(q[((((size_t)nt * ng + g) * 3 + dz) * 64 + lane) * 4 + jj] == wi[((size_t)co * Ci + ci) * 27 + (dz * 3 + dy) * 3 + dx]);
+      }
+      std::vector<float> w2((size_t)Co * Ci);
+      for (auto &v : w2) v = U(rng);
+      const std::vector<float> qs = pack_qr_skip(w2.data(), Co, Ci);
+      EXPECT(qs.size() == w2.size());
+      for (int probe = 0; probe < 100; ++probe) {
+        const int co = (int)(rng() % Co), ci = (int)(rng() % Ci);
+        EXPECT(qs[(((size_t)(co / 32) * (Ci / 8) + ci / 8) * 64 + 32 * ((ci % 8) / 4) + co % 32) * 4 + ci % 4] == w2[(size_t)co * Ci + ci]);
+      }
+      // pack_f16d: two halves per float, [nt][c16][tap][nb][lane][8]
+      for (int NB : {1, 2}) {
+        if (Co % (32 * NB) || Ci % 16) continue;
+        const std::vector<float> f = pack_f16d(wi.data(), Co, Ci, 27, NB);
+        EXPECT(f.size() * 2 == wi.size());
+        const uint16_t *h = reinterpret_cast<const uint16_t *>(f.data());
+        for (int probe = 0; probe < 100; ++probe) {
+          const int co = (int)(rng() % Co), ci = (int)(rng() % Ci), t = (int)(rng() % 27);
+          const int nt = co / (32 * NB), nb = (co % (32 * NB)) / 32, c = ci / 16, lane = 32 * ((ci % 16) / 8) + co % 32, j = ci % 8;
+          const size_t o = (((((size_t)nt * (Ci / 16) + c) * 27 + t) * NB + nb) * 64 + lane) * 8 + j;
+          EXPECT(h[o] == f32_to_f16_bits(wi[((size_t)co * Ci + ci) * 27 + t]));
+        }
+      }
+    }
+  // tile planner of the direct f16 kernel: every reference grid level gets a tile that divides it and fits the kernel's limits
+  const int grids[][3] = {{8, 12, 36}, {4, 6, 18}, {8, 28, 24}, {4, 14, 12}, {8, 24, 72}, {4, 12, 36}};
+  for (auto &g : grids) {
+    int bz = 0, by = 0, bx = 0, mbw = 0;
+    EXPECT(cm::conv_f16d_pick(g[0], g[1], g[2], &bz, &by, &bx, &mbw));
+    EXPECT(g[0] % bz == 0 && g[1] % by == 0 && g[2] % bx == 0 && bz * by * bx <= 128 * mbw && mbw >= 1 && mbw <= 2);
+    cm::ConvArgs a{};
+    a.ntaps = 27; a.stride = 1; a.C0 = 32; a.Co = 32; a.Zs = a.Zo = g[0]; a.Ys = a.Yo = g[1]; a.Xs = a.Xo = g[2]; a.bz = bz; a.by = by; a.bx = bx;
+    EXPECT(cm::conv_f16d_ok(a, mbw) && cm::conv_f16d_slots(a, mbw) <= MAX_SLOTS);
+  }
+  // the whole-sample kernel accepts the quarter resolution of the ATC / CR-120 grids and refuses what it cannot stage
+  cm::QrArgs q{};
+  q.C0 = 128; q.Co = 128; q.groups = 8; q.Y = 3; q.X = 9;
+  EXPECT(cm::conv_qr_ok(q));
+  q.Y = 7; q.X = 6; q.C1 = 128;
+  EXPECT(cm::conv_qr_ok(q));
+  q.Y = 6; q.X = 18;
+  EXPECT(!cm::conv_qr_ok(q));                       // 108 voxels per plane
+  q.Y = 3; q.X = 9; q.Co = 48;
+  EXPECT(!cm::conv_qr_ok(q));
+}
+
 void test_misc_errors() {
   EXPECT(cm_abi_version() == CM_ABI_VERSION);
   EXPECT(cm_device_count(nullptr) != 0);
@@ -212,6 +273,7 @@ int main() {
   test_plan_and_params();
   test_packers();
   test_tile_planner();
+  test_round3_packers();
   test_misc_errors();
   printf("selftest ok: %d checks\n", g_checks);
   return 0;
