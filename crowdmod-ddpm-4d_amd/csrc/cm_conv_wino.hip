@@ -419,8 +419,8 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
 #pragma unroll
       for (int x = 0; x < 4; ++x) af[x] = *reinterpret_cast<const f32x4 *>(arow + (size_t)x * UR * S + (size_t)dz * NP * S + acol);
     };
-    f32x4 afc[4], afn[4];
-    aread(0, afc);
+    f32x4 afr[2][4];                         // A fragments of the current / next group (static parity: no register copies)
+    aread(0, afr[0]);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       // refill the other ring slot with the next group (possibly the next chunk's first)
@@ -432,21 +432,19 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
           for (int x = 0; x < 4; ++x) bq[(g + 1) % RS][x] = wn[x * 64];
         }
       }
-      if (g + 1 < NG) aread(g + 1, afn);
+      if (g + 1 < NG) aread(g + 1, afr[(g + 1) & 1]);
       asm volatile("" ::: "memory");          // next group's weights and A fragments are REQUESTED here, not at their first use
       if constexpr (F16) {
 #pragma unroll
         for (int x = 0; x < 4; ++x)
-          acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afc[x]), __builtin_bit_cast(f16x8, bq[g % RS][x]), acc[x], 0, 0, 0);
+          acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[g & 1][x]), __builtin_bit_cast(f16x8, bq[g % RS][x]), acc[x], 0, 0, 0);
       } else {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
           for (int x = 0; x < 4; ++x)
-            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(afc[x][jj], bq[g % RS][x][jj], acc[x], 0, 0, 0);
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[g & 1][x][jj], bq[g % RS][x][jj], acc[x], 0, 0, 0);
       }
-#pragma unroll
-      for (int x = 0; x < 4; ++x) afc[x] = afn[x];
     }
   }
 
