@@ -180,3 +180,38 @@ def test_training_step_b128_reproduces_the_b2_reference_gradients():
             got = net.grad(key[7:])[:4, :4]
             assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-8, key
     assert n == 168
+
+
+def test_two_lane_loop_with_injected_noise_and_history_equals_b2_loops():
+    """The default two batch lanes (B >= 16) with caller-supplied x_T / per-step noise and the step history: lane offsets into the
+    injected tensors and the history buffer must address the same chains as single-lane B = 2 loops (ddpm.py:206-236)."""
+    from crowdmod_ddpm_4d_amd.config import AttrDict
+    from crowdmod_ddpm_4d_amd.ddpm_model import DDPM_model
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    from helpers import narrow_cfg, NARROW
+    C_, B, T = 3, 16, 6
+    H, W, P, F = NARROW["H"], NARROW["W"], NARROW["P"], NARROW["F"]
+
+    def model(batch):
+        cfg = AttrDict({
+            "MACROPROPS": {"ROWS": H, "COLS": W}, "DATASET": {"PAST_LEN": P, "FUTURE_LEN": F, "BATCH_SIZE": batch},
+            "MODEL": {"NSAMPLES": batch, "NSAMPLES4PLOTS": 2, "DDPM": {
+                "SAMPLER": "DDPM", "TIMESTEPS": T, "SCALE": 0.5, "SIGMA": 0.001, "DDIM_DIVIDER": 2, "GUIDANCE": "None", "LAMBDA_GUIDANCE": 0.0,
+                "UNET": {"CONDITION": "Past", "NUM_RES_BLOCKS": 1, "BASE_CH": 8, "BASE_CH_MULT": [1, 2, 4],
+                         "APPLY_ATTENTION": [False, False, True, False], "DROPOUT_RATE": 0.1, "TIME_EMB_MULT": 4}}}})
+        m = DDPM_model(cfg, "DDPM-UNet", C_)
+        m.denoiser.load_state_dict(spec.init_params(narrow_cfg(C_), SEED_W))
+        return m
+    per = C_ * H * W * F
+    past = prng.normal(7, "lanes2/past", B * C_ * H * W * P).reshape(B, C_, H, W, P)
+    x_T = prng.normal_per_sample(7, "lanes2/xT", np.arange(B), per).reshape(B, C_, H, W, F)
+    noise = np.stack([prng.normal_per_sample(7, "lanes2/z", np.arange(B), per, step=t).reshape(B, C_, H, W, F) for t in range(T - 1, 0, -1)])
+    sampler = DDPM(timesteps=T, scale=0.5)
+    xB, histB = model(B)._generate_ddpm(past, sampler, B, history=True, x_T=x_T, noise=noise)
+    assert np.isfinite(xB).all() and len(histB) == T + 1
+    m2 = model(2)
+    for i in (0, 6, 8, 14):                       # chains of both lanes (lane 1 starts at chain 8)
+        x2, hist2 = m2._generate_ddpm(past[i:i + 2], sampler, 2, history=True, x_T=x_T[i:i + 2], noise=noise[:, i:i + 2])
+        assert np.array_equal(x2, xB[i:i + 2]), i
+        for k in (0, 1, T // 2, T):
+            assert np.array_equal(np.asarray(hist2[k]), np.asarray(histB[k])[i:i + 2]), (i, k)
