@@ -525,7 +525,7 @@ def gen_energy(out):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="schedule,ops,fwd,loop,train,train_full,fm,metrics")
+    ap.add_argument("--only", default="schedule,ops,fwd,loop,train,train_full,fm,metrics,energy")
     ap.add_argument("--out", default=HERE)
     a = ap.parse_args()
     torch.manual_seed(0)
