@@ -221,10 +221,15 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
     outoff[tid] = (own && b0 < a.B && oz < a.Zo && oy < a.Yo && ox < a.Xo) ? ((b0 * a.Zo + oz) * a.Yo + oy) * a.Xo + ox : -1;
   }
   // ---- this thread's staging item: source voxel offsets of its 4x4 patch, resolved once ---------------
+  // TWO: halo planes outside the grid (z0 - 1 < 0, z0 + BZ >= Zs) are zero padding for EVERY chunk: their rows of R and U are
+  // zeroed once below and neither staged nor transformed -- at full resolution (BZ = Zo) that is 2 of the 10 planes, on the
+  // two-tile half-resolution launches 1 of 4: a fifth / quarter of the activation and transform instructions of a chunk
+  const int pad_lo = (TWO && z0 == 0) ? 1 : 0, pad_hi = (TWO && z0 + BZ >= a.Zs) ? 1 : 0;
+  const int nreal = HZ - pad_lo - pad_hi;          // (workgroup-uniform)
   const int itid = HALF ? tid >> 1 : tid, hf = HALF ? tid & 1 : 0;   // HALF: lane pair = item, hf = its patch rows {2hf, 2hf+1}
-  const bool stager = itid < NITEMS;
+  const bool stager = itid < (TWO ? nreal * NP * (CS / 4) : NITEMS);
   const int it = stager ? itid : 0;
-  const int quad = it & 3, patch = (it >> 2) % NP, zi = it / (4 * NP);
+  const int quad = it & 3, patch = (it >> 2) % NP, zi = it / (4 * NP) + pad_lo;
   constexpr int NR = HALF ? 2 : 4;              // patch rows this thread loads
   int soff[NR * 4];
   unsigned okmask = 0;
@@ -247,13 +252,15 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
   // TWO, step A: voxel (tid >> 2) + 64 k of the halo box, channel quad tid & 3
   int asoff[RK];
   unsigned aok = 0;
+  const int RVR = (pad_lo + nreal) * (RYH * RXH);   // end of the real planes in the halo-voxel numbering
+  const int rkr = TWO ? (nreal * (RYH * RXH) * 4 + NT - 1) / NT : 0;   // step-A rounds that hold real voxels (<= RK)
   if constexpr (TWO) {
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
-      const int v = (tid >> 2) + (NT / 4) * k;
+      const int v = (tid >> 2) + (NT / 4) * k + pad_lo * (RYH * RXH);     // voxel of the real planes only
       const int vz = v / (RYH * RXH), rem = v - vz * (RYH * RXH), vy = rem / RXH, vx = rem - vy * RXH;
       const int cz = z0 - 1 + vz, cy = y0 - 1 + vy, cx = x0 - 1 + vx;
-      const bool ok = v < RV && b0 < a.B && cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs;
+      const bool ok = v < RVR && b0 < a.B && cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs;
       asoff[k] = ok ? ((bs * a.Zs + cz) * a.Ys + cy) * a.Xs + cx : 0;
       aok |= (ok ? 1u : 0u) << k;
     }
@@ -288,7 +295,19 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
   if constexpr (TWO) {
     const float *sp0 = a.src0 + 4 * aq;          // chunk 0 always comes from src0
 #pragma unroll
-    for (int k = 0; k < RK; ++k) ald[k] = *reinterpret_cast<const f32x4 *>(sp0 + (size_t)asoff[k] * a.C0);
+    for (int k = 0; k < RK; ++k)
+      if (k < rkr) ald[k] = *reinterpret_cast<const f32x4 *>(sp0 + (size_t)asoff[k] * a.C0);
+    // zero the padding planes of R and U once (no chunk ever writes them)
+    for (int pz = 0; pz < 2; ++pz) {
+      if (!(pz ? pad_hi : pad_lo)) continue;
+      const int plane = pz ? HZ - 1 : 0;
+      for (int i = tid; i < RYH * RXH * (RS_ / 4); i += NT)
+        *reinterpret_cast<f32x4 *>(R + (size_t)plane * (RYH * RXH) * RS_ + 4 * i) = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = tid; i < 16 * NP * (S / 4); i += NT) {
+        const int xi = i / (NP * (S / 4)), rem = i - xi * (NP * (S / 4));
+        *reinterpret_cast<f32x4 *>(U + ((size_t)xi * UR + plane * NP) * S + 4 * rem) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
   }
 
   f32x4 dn[TWO ? 1 : NR * 4];                    // one-step form: raw patch loads of the NEXT chunk, in flight during the matrix phase
@@ -325,23 +344,24 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
       if (a.dbg & 128) {                        // diagnostic: plain copy instead of GroupNorm + SiLU
 #pragma unroll
         for (int k = 0; k < RK; ++k) {
-          const int v = (tid >> 2) + (NT / 4) * k;
-          if (v < RV) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = ald[k];
+          const int v = (tid >> 2) + (NT / 4) * k + pad_lo * (RYH * RXH);
+          if (k < rkr && v < RVR) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = ald[k];
         }
       } else if (a.gn && a.silu && !a.pm) {     // (workgroup-uniform: the plain ResnetBlock conv; no selects on the flags)
 #pragma unroll
-        for (int k = 0; k < RK; ++k) {
-          const int v = (tid >> 2) + (NT / 4) * k;
-          f32x4 w = ald[k] * sc1 + sh1;
-          w[0] = silu_w(w[0]); w[1] = silu_w(w[1]); w[2] = silu_w(w[2]); w[3] = silu_w(w[3]);
-          if (!((aok >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (v < RV) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = w;
-        }
+        for (int k = 0; k < RK; ++k)
+          if (k < rkr) {
+            const int v = (tid >> 2) + (NT / 4) * k + pad_lo * (RYH * RXH);
+            f32x4 w = ald[k] * sc1 + sh1;
+            w[0] = silu_w(w[0]); w[1] = silu_w(w[1]); w[2] = silu_w(w[2]); w[3] = silu_w(w[3]);
+            if (!((aok >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (v < RVR) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = w;
+          }
       } else {
 #pragma unroll
         for (int k = 0; k < RK; ++k) {
-          const int v = (tid >> 2) + (NT / 4) * k;
-          if (v < RV) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = activate(ald[k], (aok >> k) & 1u);
+          const int v = (tid >> 2) + (NT / 4) * k + pad_lo * (RYH * RXH);
+          if (k < rkr && v < RVR) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = activate(ald[k], (aok >> k) & 1u);
         }
       }
       __syncthreads();                        // R complete; every wave is past the previous chunk's matrix phase
@@ -405,7 +425,8 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
       const int Cn = cn < n0 ? a.C0 : a.C1;
       if constexpr (TWO) {
 #pragma unroll
-        for (int k = 0; k < RK; ++k) ald[k] = *reinterpret_cast<const f32x4 *>(spn + (size_t)asoff[k] * Cn);
+        for (int k = 0; k < RK; ++k)
+          if (k < rkr) ald[k] = *reinterpret_cast<const f32x4 *>(spn + (size_t)asoff[k] * Cn);
       } else if constexpr (PRE) {
 #pragma unroll
         for (int k = 0; k < NR * 4; ++k) dn[k] = *reinterpret_cast<const f32x4 *>(spn + (size_t)soff[k] * Cn);
