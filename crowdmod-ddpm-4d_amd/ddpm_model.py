@@ -383,7 +383,9 @@ class DDPM_model:
         if eps is None:
             mp = self.cfg.get("MACROPROPS", {}) if hasattr(self.cfg, "get") else {}
             eps = float(mp.get("EPS", 1e-6)) if hasattr(mp, "get") else 1e-6
-        compute_metrics(mg, metric, chunk, eps)
+        mt = self.cfg.get("METRICS", {}) if hasattr(self.cfg, "get") else {}
+        mf = mt.get("MOTION_FEATURE", None) if hasattr(mt, "get") else None    # f, k, GAMMA (metricsGenerator.py:244-245)
+        compute_metrics(mg, metric, chunk, eps, motion_feature=mf)
         if output_dir:
             title = f"{r.batch_size * chunk * count} samples in total (BS:{r.batch_size}, Rep:{chunk}, TB:{count})-({self.arch})"
             mg.save_data_metrics(output_dir, title, samples_per_batch)

@@ -5,7 +5,8 @@ Mirror of the reduction-type metrics of the reference's `MetricsGenerator`
 sequence, + per-frame tables), relative density error (+ MIN), total variation over time.  The reference loops
 over every sample and frame in Python on `.cpu()` copies; here one kernel (cm_frame_metrics) reduces
 `[N,C,H,W,F]` to `[N,C,F]` partial sums and only those come back.  SSIM and the energy metric run on the host
-(scipy / numpy), as the reference's own do (skimage / torch CPU); the motion-feature histograms are not built."""
+(scipy / numpy), as the reference's own do (skimage / torch CPU), and so do the motion-feature histogram metrics
+(MF_MSE, MF_BHATT: numpy, vectorised over all volumes)."""
 from __future__ import annotations
 
 import numpy as np
@@ -87,6 +88,94 @@ def energy_tables(pred, gt, chunk, mprops_factor=None):
     return {"ENERGY": e, "MIN-ENERGY": mn}
 
 
+# ---- motion-feature histograms (utils/metrics/motionFeatureExtractor.py) ---------------------------------------------------
+def _mf_polar(seq):
+    """MotionFeatureExtractor.compute_norm_angle_4samples + mag_rho_transform (motionFeatureExtractor.py:34-59) for all
+    sequences at once.  seq: [N, C, r, c, F] (channel 1 = v_x, 2 = v_y) -> (log-magnitude, angle), each [N, F, r, c] float64.
+    The magnitude and the angle are formed in float32 (the reference's tensors) and widened; the magnitude is min-max scaled
+    to [0, 255] PER GRID CELL over the F frames of its sequence (sklearn's MinMaxScaler sees an [F, r c] matrix: one feature
+    per cell; a cell whose magnitude does not change maps to 0) and compressed with log2(1 + .) to [0, 8]."""
+    seq = np.asarray(seq, dtype=np.float32)
+    vx, vy = np.moveaxis(seq[:, 1], -1, 1), np.moveaxis(seq[:, 2], -1, 1)          # [N, F, r, c]
+    mag = np.sqrt(vx * vx + vy * vy).astype(np.float64)
+    ang = np.arctan2(vy, vx).astype(np.float64)
+    lo, hi = mag.min(axis=1, keepdims=True), mag.max(axis=1, keepdims=True)
+    rng = hi - lo
+    rng = np.where(rng < 10 * np.finfo(np.float64).eps, 1.0, rng)                  # sklearn _handle_zeros_in_scale
+    scale = 255.0 / rng
+    return np.log2(mag * scale + (0.0 - lo * scale) + 1.0), ang
+
+
+def _mf_bins(x, lo, hi, nbins):
+    """Bin index as np.histogram2d / np.digitize(x, np.linspace(lo, hi, nbins + 1)) - 1 assign it: right-open bins found with
+    searchsorted(side='right'); -1 / nbins = outside.  `closed`: histogram2d also takes x == hi into the last bin."""
+    edges = np.linspace(lo, hi, nbins + 1)
+    return np.searchsorted(edges, x, side="right") - 1, edges
+
+
+def motion_feature_vectors(seq, f, k, gamma, num_magnitude_bins=16, num_angle_bins=16):
+    """The two motion-feature vectors of every sequence as get_motion_feature_2D_hist / get_motion_feature_1D_hist build
+    them (motionFeatureExtractor.py:166-284): the sequence is cut into volumes of f frames x k x k cells (ragged at the far
+    edges); per volume
+      2-D: counts over (log-magnitude in [0, 8], angle in [-pi, pi]) with 16 x 16 bins, the whole first magnitude bin moved to
+           the angle bin 8 ("angle 0" for motionless cells);
+      1-D: per angle bin the sum of log-magnitude ** gamma;
+    the volumes' histograms are concatenated in (frame block, row block, column block) order and divided by (their sum + 1).
+    One pass of integer bin indices + np.add.at instead of the reference's histogram call per volume.
+    Returns (mf2d [N, nvol * 256], mf1d [N, nvol * 16])."""
+    mag, ang = _mf_polar(seq)
+    N, F, r, c = mag.shape
+    nm, na = int(num_magnitude_bins), int(num_angle_bins)
+    nvf, nvr, nvc = -(-F // f), -(-r // k), -(-c // k)
+    vol = ((np.arange(F) // f)[:, None, None] * nvr + (np.arange(r) // k)[None, :, None]) * nvc + (np.arange(c) // k)[None, None, :]
+    vol = np.broadcast_to(vol[None], mag.shape)
+    nvol = nvf * nvr * nvc
+    mb, _ = _mf_bins(mag, 0.0, 8.0, nm)
+    ab, _ = _mf_bins(ang, -np.pi, np.pi, na)
+    samp = np.broadcast_to(np.arange(N)[:, None, None, None], mag.shape)
+    # 2-D counts: histogram2d keeps x == right edge in the last bin and drops everything else outside the range
+    mb2 = np.where(mag == 8.0, nm - 1, mb)
+    ab2 = np.where(ang == np.pi, na - 1, ab)
+    ok = (mb2 >= 0) & (mb2 < nm) & (ab2 >= 0) & (ab2 < na)
+    h2 = np.zeros((N, nvol, nm, na))
+    np.add.at(h2, (samp[ok], vol[ok], mb2[ok], ab2[ok]), 1.0)
+    first = h2[:, :, 0, :].sum(axis=2)                       # set_zero_angle_to_smallMag
+    h2[:, :, 0, :] = 0.0
+    h2[:, :, 0, na // 2] = first
+    mf2 = h2.reshape(N, -1)
+    mf2 = mf2 / (mf2.sum(axis=1, keepdims=True) + 1.0)
+    # 1-D weighted sums: np.digitize has no closed last bin (an angle of exactly +pi is dropped)
+    ok1 = (ab >= 0) & (ab < na)
+    h1 = np.zeros((N, nvol, na))
+    np.add.at(h1, (samp[ok1], vol[ok1], ab[ok1]), np.power(mag[ok1], gamma))
+    mf1 = h1.reshape(N, -1)
+    mf1 = mf1 / (mf1.sum(axis=1, keepdims=True) + 1.0)
+    return mf2, mf1
+
+
+def bhattacharyya(P, Q, epsilon=1e-2):
+    """get_bhattacharyya_dist_coef (motionFeatureExtractor.py:286-303) row-wise: coefficient sum sqrt(P Q) clipped to
+    [epsilon, 1], distance -log(coefficient)."""
+    coef = np.clip(np.sqrt(np.asarray(P) * np.asarray(Q)).sum(axis=-1), epsilon, 1.0)
+    return -np.log(coef), coef
+
+
+def motion_feature_tables(pred, gt, f, k, gamma, mse_metric=True, bhatt_metrics=True):
+    """MetricsGenerator.compute_motion_feature_metrics (metricsGenerator.py:93-112, 240-258): per sample the (2-D based,
+    1-D based) mean squared error / Bhattacharyya distance and coefficient between the ground-truth and predicted vectors."""
+    p2, p1 = motion_feature_vectors(pred, f, k, gamma)
+    g2, g1 = motion_feature_vectors(gt, f, k, gamma)
+    out = {"MF_MSE": None, "MF_BHATT_DIST": None, "MF_BHATT_COEF": None}
+    if mse_metric:
+        out["MF_MSE"] = np.stack([((g2 - p2) ** 2).mean(axis=1), ((g1 - p1) ** 2).mean(axis=1)], axis=1)
+    if bhatt_metrics:
+        d2, c2 = bhattacharyya(g2, p2)
+        d1, c1 = bhattacharyya(g1, p1)
+        out["MF_BHATT_DIST"] = np.stack([d2, d1], axis=1)
+        out["MF_BHATT_COEF"] = np.stack([c2, c1], axis=1)
+    return out
+
+
 class MetricsGenerator:
     def __init__(self, pred, gt, mprops_count: int = 3, device: int = 0):
         """pred / gt: arrays [N, C, H, W, F] (or lists of [C,H,W,F] sequences like the reference takes)."""
@@ -163,6 +252,11 @@ class MetricsGenerator:
         pred, gt = self._pred_gt
         self.data_dict.update(energy_tables(pred, gt, chunkRepdPastSeq, mprops_factor))
 
+    def compute_motion_feature_metrics(self, mse_metric=False, bhatt_metrics=False, f=1, k=4, gamma=0.5):
+        """metricsGenerator.py:240-258, on the host (numpy), like the reference's; f / k / gamma = METRICS.MOTION_FEATURE."""
+        pred, gt = self._pred_gt
+        self.data_dict.update(motion_feature_tables(pred, gt, int(f), int(k), float(gamma), mse_metric, bhatt_metrics))
+
     def compute_tv_metric(self):
         """metricsGenerator.py:319-339: |TV(pred) - TV(gt)| per (frame, property)."""
         m = self.mprops_count
@@ -179,7 +273,9 @@ class MetricsGenerator:
                 "MASK_PSNR": flat, "MAX_MASK_PSNR": flat, "MASK_PSNR_OVER_TIME": per_frame, "MAX_MASK_PSNR_OVER_TIME": per_frame,
                 "RE_DENSITY": frames, "MIN_RE_DENSITY": frames, "TV_OVER_TIME": per_frame,
                 "SSIM": flat, "MAX_SSIM": flat, "SSIM_OVER_TIME": per_frame, "MAX_SSIM_OVER_TIME": per_frame,
-                "ENERGY": "GT,PRED", "MIN-ENERGY": "GT,PRED"}
+                "ENERGY": "GT,PRED", "MIN-ENERGY": "GT,PRED", "MF_MSE": "MSE_Hist_2D_Based,MSE_Hist_1D_Based",
+                "MF_BHATT_DIST": "BHATT_DIST_Hist_2D_Based,BHATT_DIST_Hist_1D_Based",
+                "MF_BHATT_COEF": "BHATT_COEF_Hist_2D_Based,BHATT_COEF_Hist_1D_Based"}
 
     def save_data_metrics(self, output_dir, title, samples_per_batch):
         import json
@@ -198,18 +294,25 @@ class MetricsGenerator:
         return index
 
 
-def compute_metrics(mg: MetricsGenerator, metric: str, chunkRepdPastSeq: int, eps: float):
-    """utils/metrics/metricsGenerator.py:379-395 for the metrics this path implements."""
-    known = ("PSNR", "MASK_PSNR", "SSIM", "ENERGY", "RE_DENSITY", "TV", "ALL")
+def compute_metrics(mg: MetricsGenerator, metric: str, chunkRepdPastSeq: int, eps: float, motion_feature=None):
+    """utils/metrics/metricsGenerator.py:379-395.  `motion_feature`: the METRICS.MOTION_FEATURE mapping (f, k, GAMMA) of the
+    config.  The reference's command line advertises MOTION_FEAT_BHATT (generate_metrics.py:74) while its dispatcher tests
+    for MF_BHATT: both spellings select the Bhattacharyya tables here."""
+    if metric == "MOTION_FEAT_BHATT":
+        metric = "MF_BHATT"
+    known = ("PSNR", "MASK_PSNR", "SSIM", "MF_MSE", "MF_BHATT", "ENERGY", "RE_DENSITY", "TV", "ALL")
     if metric not in known:
-        raise ValueError(f"metric {metric!r}: this path computes {known}; MF_MSE / MF_BHATT (motion-feature histograms, "
-                         f"utils/metrics/motionFeatureExtractor.py) are not built")
+        raise ValueError(f"metric {metric!r}: this path computes {known}")
     if metric in ("PSNR", "ALL"):
         mg.compute_psnr_metric(chunkRepdPastSeq, eps)
     if metric in ("MASK_PSNR", "ALL"):
         mg.compute_psnr_metric(chunkRepdPastSeq, eps, masked_flag=True)
     if metric in ("SSIM", "ALL"):
         mg.compute_ssim_metric(chunkRepdPastSeq)
+    if metric in ("MF_MSE", "MF_BHATT", "ALL"):
+        mf = dict(motion_feature or {})
+        mg.compute_motion_feature_metrics(metric in ("MF_MSE", "ALL"), metric in ("MF_BHATT", "ALL"),
+                                          f=mf.get("f", 1), k=mf.get("k", 4), gamma=mf.get("GAMMA", 0.5))
     if metric == "ENERGY":                      # (the reference lists it under the misspelt 'ALLA': never part of ALL)
         mg.compute_energy_metric(chunkRepdPastSeq)
     if metric in ("RE_DENSITY", "ALL"):

@@ -5,7 +5,7 @@ For every test batch: `samples_per_batch / chunk` past windows, each repeated `c
 device loop (cfg MODEL.NSAMPLES = 1280 = 64 pasts x 20 repeats by default), and the per-frame reductions behind
 PSNR / masked PSNR / relative density error / total variation run on the device too (cm_frame_metrics); the
 tables land in <OUTPUT_DIR>/metrics as CSV + metrics_files.json.  SSIM and ENERGY run on the host (scipy / numpy), as
-the reference's do (skimage / torch CPU); the motion-feature histogram metrics are not built.
+the reference's do (skimage / torch CPU), and so do the motion-feature histogram metrics MF_MSE / MF_BHATT.
 
 Data: `--data-npy` takes sequences [N, C>=3, ROWS, COLS, T] cut into past/future windows (utils/dataset.py:22-53);
 without it synthetic windows ~ N(0,1) with a non-negative density channel are used (no dataset ships here).
@@ -24,7 +24,7 @@ from crowdmod_ddpm_4d_amd import config as cfgmod, prng  # noqa: E402
 def main(argv=None):
     ap = argparse.ArgumentParser(description="A script to generate metrics from a trained model (MI355X-native path).")
     ap.add_argument('--chunk-repd-past-seq', type=int, default=None, help='Chunk of repeated past sequences to use when predicting.')
-    ap.add_argument('--metric', type=str, default='ALL', help='PSNR|MASK_PSNR|SSIM|ENERGY|RE_DENSITY|TV|ALL (MF_MSE / MF_BHATT: not built)')
+    ap.add_argument('--metric', type=str, default='ALL', help='PSNR|MASK_PSNR|SSIM|MF_MSE|MF_BHATT (= MOTION_FEAT_BHATT)|ENERGY|RE_DENSITY|TV|ALL')
     ap.add_argument('--batches-to-use', type=int, default=1, help='Total of batches to use to compute metrics.')
     ap.add_argument('--config-yml-file', type=str, default='config/ATC.yml')
     ap.add_argument('--configList-yml-file', type=str, default=None)

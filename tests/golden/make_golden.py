@@ -18,6 +18,7 @@ What is captured:
                     _generate_ddim divider 50 on CR-120
   train_full_cr120.npz  (--only train_grids) full-width training step on the CR-120 grid
   energy.npz        (--only energy) models/guidance.py compute_energy on synthetic sequences
+  motion_feat.npz   (--only motion_feat) utils/metrics/motionFeatureExtractor.py vectors + MF_MSE / MF_BHATT tables
 
 Weights and inputs are NOT stored: both sides regenerate them bit-identically
 from the integer PRNG (crowdmod-ddpm-4d_amd/prng.py, spec.init_params).
@@ -523,9 +524,48 @@ def gen_energy(out):
     print("energy", d["e11"][:3])
 
 
+def gen_motion_feat(out):
+    """utils/metrics/motionFeatureExtractor.py + MetricsGenerator.compute_motion_feature_metrics (metricsGenerator.py:240-258)
+    on synthetic velocity fields: the two motion-feature vectors of every sequence and the MF_MSE / MF_BHATT tables, for
+    the ATC setting (f 1, k 4, gamma 0.5) and a ragged one (f 2, k 5, gamma 2: volumes cut off at the far edges).  The
+    reference's histogram plots (matplotlib, drawn for a random 5 % of the volumes) are switched off."""
+    AttrDict = _placeholders()
+    import utils.metrics.motionFeatureExtractor as MFE
+    import utils.metrics.metricsGenerator as MG
+    for mod in (MFE, MG):
+        for fn in ("plot_motion_feat_hist2D", "plot_motion_feat_hist1D"):
+            if hasattr(mod, fn):
+                setattr(mod, fn, lambda *a, **k: None)
+    N, C, H, W, F = 6, 3, 12, 36, 3
+    gt = prng.normal(SEED_X, "mf/gt", N * C * H * W * F).reshape(N, C, H, W, F)
+    gt[:, 1:3, :3, :, :] = 0.0                      # motionless cells (first magnitude bin, angle 0)
+    gt[:, 1:3, 3:5, :, :] = gt[:, 1:3, 3:5, :, :1]  # cells whose velocity never changes (zero range under the min-max scaling)
+    gt[0, 1, 6, :, :] = -np.abs(gt[0, 1, 6, :, :])  # angles of exactly +pi (v_y = +0) and -pi ... (v_y = -0)
+    gt[0, 2, 6, :18, :] = 0.0
+    gt[0, 2, 6, 18:, :] = -0.0
+    pred = gt + 0.4 * prng.normal(SEED_X, "mf/noise", gt.size).reshape(gt.shape)
+    pred[:, 1:3, :2] = 0.0
+    gt, pred = gt.astype(np.float32), pred.astype(np.float32)
+    d = {"gt": gt, "pred": pred}
+    for tag, f, k, gamma in (("atc", 1, 4, 0.5), ("ragged", 2, 5, 2.0)):
+        params = AttrDict({"MPROPS_COUNT": 3, "MOTION_FEATURE": {"f": f, "k": k, "GAMMA": gamma}})
+        mg = MG.MetricsGenerator([torch.from_numpy(p) for p in pred], [torch.from_numpy(g) for g in gt], params, None)
+        mg.compute_motion_feature_metrics(True, True)
+        ep = MFE.MotionFeatureExtractor(mg.pred_seq_list, f=f, k=k, gamma=gamma)
+        eg = MFE.MotionFeatureExtractor(mg.gt_seq_list, f=f, k=k, gamma=gamma)
+        p2, g2 = MFE.get_motion_feature_2D_hist(ep, eg)
+        p1, g1 = MFE.get_motion_feature_1D_hist(ep, eg)
+        d.update({f"{tag}/fkg": np.array([f, k, gamma]), f"{tag}/p2": p2, f"{tag}/g2": g2, f"{tag}/p1": p1, f"{tag}/g1": g1,
+                  f"{tag}/mag": ep.mag_rho_transf, f"{tag}/ang": ep.angle_phi})
+        for name in ("MF_MSE", "MF_BHATT_DIST", "MF_BHATT_COEF"):
+            d[f"{tag}/{name}"] = np.asarray(mg.data_dict[name], dtype=np.float64)
+        print("motion features", tag, p2.shape, p1.shape, d[f"{tag}/MF_BHATT_COEF"][0])
+    np.savez_compressed(os.path.join(out, "motion_feat.npz"), **d)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="schedule,ops,fwd,loop,train,train_full,fm,metrics,energy")
+    ap.add_argument("--only", default="schedule,ops,fwd,loop,train,train_full,fm,metrics,energy,motion_feat")
     ap.add_argument("--out", default=HERE)
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -546,6 +586,8 @@ def main():
         gen_metrics(a.out)
     if "energy" in todo:
         gen_energy(a.out)
+    if "motion_feat" in todo:
+        gen_motion_feat(a.out)
     if "loop" in todo:
         gen_loop(a.out)
     if "train_grids" in todo:

@@ -579,3 +579,35 @@ def test_ssim_restatement_against_brute_force_and_its_identities():
     assert np.allclose(t["MAX_SSIM_OVER_TIME"][1], t["SSIM_OVER_TIME"][2:4].max(axis=0))
     with pytest.raises(ValueError):
         metrics._ssim2d(x[:5], y[:5], R)
+
+
+def test_motion_feature_metrics_match_the_reference_extractor():
+    """MF_MSE / MF_BHATT (missing item of the round-2 review): the vectorised motion-feature histograms against the vectors
+    and tables the reference's own MotionFeatureExtractor / MetricsGenerator produced on the same sequences
+    (tests/golden/motion_feat.npz, generated by importing the reference) -- ATC setting and a ragged one (f 2, k 5, gamma 2),
+    with motionless cells, constant cells and angles of exactly +-pi in the data.  Counts are integers: exact."""
+    from crowdmod_ddpm_4d_amd import metrics
+    g = load("motion_feat.npz")
+    for tag in ("atc", "ragged"):
+        f, k, gamma = g[f"{tag}/fkg"]
+        mag, ang = metrics._mf_polar(g["pred"])
+        N = mag.shape[0]
+        np.testing.assert_array_equal(mag.reshape(N, mag.shape[1], -1), g[f"{tag}/mag"])
+        np.testing.assert_array_equal(ang.reshape(N, ang.shape[1], -1), g[f"{tag}/ang"])
+        p2, p1 = metrics.motion_feature_vectors(g["pred"], int(f), int(k), float(gamma))
+        g2, g1 = metrics.motion_feature_vectors(g["gt"], int(f), int(k), float(gamma))
+        np.testing.assert_array_equal(p2, g[f"{tag}/p2"])
+        np.testing.assert_array_equal(g2, g[f"{tag}/g2"])
+        np.testing.assert_allclose(p1, g[f"{tag}/p1"], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(g1, g[f"{tag}/g1"], rtol=1e-12, atol=1e-15)
+        t = metrics.motion_feature_tables(g["pred"], g["gt"], int(f), int(k), float(gamma))
+        for name in ("MF_MSE", "MF_BHATT_DIST", "MF_BHATT_COEF"):
+            assert t[name].shape == (N, 2)
+            np.testing.assert_allclose(t[name], g[f"{tag}/{name}"], rtol=1e-10, atol=1e-15)
+    # identical sequences: coefficient sum(P) = S / (S + 1) < 1, distance -log of it; disjoint ones clip at epsilon
+    same = metrics.motion_feature_tables(g["gt"], g["gt"], 1, 4, 0.5)
+    assert np.all(same["MF_MSE"] == 0) and np.all(same["MF_BHATT_COEF"] <= 1.0) and np.all(same["MF_BHATT_COEF"] > 0.99)
+    d, c = metrics.bhattacharyya(np.array([[1.0, 0.0]]), np.array([[0.0, 1.0]]))
+    assert c[0] == 1e-2 and abs(d[0] + np.log(1e-2)) < 1e-15
+    only = metrics.motion_feature_tables(g["pred"], g["gt"], 1, 4, 0.5, mse_metric=False, bhatt_metrics=True)
+    assert only["MF_MSE"] is None and only["MF_BHATT_DIST"] is not None
