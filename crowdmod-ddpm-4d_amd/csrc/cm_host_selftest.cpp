@@ -238,6 +238,28 @@ void test_round3_packers() {
     a.ntaps = 27; a.stride = 1; a.C0 = 32; a.Co = 32; a.Zs = a.Zo = g[0]; a.Ys = a.Yo = g[1]; a.Xs = a.Xo = g[2]; a.bz = bz; a.by = by; a.bx = bx;
     EXPECT(cm::conv_f16d_ok(a, mbw) && cm::conv_f16d_slots(a, mbw) <= MAX_SLOTS);
   }
+  // stage-once upsample kernel: a source tile for every upsample source grid of the reference configs (ATC, CR-120, 24x72),
+  // planes tiles where a plane fits one row block; the launcher's own feasibility test agrees with the picker
+  const int srcs[][3] = {{2, 3, 9}, {4, 6, 18}, {2, 7, 6}, {4, 14, 12}, {2, 6, 18}, {4, 12, 36}};
+  for (auto &g : srcs) {
+    int tz = 0, ty = 0, tx = 0, mbw = 0, planes = 0;
+    EXPECT(cm::conv_ups_pick(g[0], g[1], g[2], &tz, &ty, &tx, &mbw, &planes));
+    EXPECT(g[0] % tz == 0 && g[1] % ty == 0 && g[2] % tx == 0 && mbw >= 1 && mbw <= 5 && (tz + 1) * (ty + 2) * (tx + 2) <= 320);
+    EXPECT(planes ? (ty * tx <= 32 && mbw == tz) : tz * ty * tx <= 32 * mbw);
+    cm::ConvArgs a{};
+    a.par = 1; a.ntaps = 8; a.td = 2; a.CK = 32; a.C0 = 64; a.Co = 64; a.Zs = g[0]; a.Ys = g[1]; a.Xs = g[2];
+    a.Zo = 2 * g[0]; a.Yo = 2 * g[1]; a.Xo = 2 * g[2]; a.bz = tz; a.by = ty; a.bx = tx; a.ntz = g[0] / tz; a.nty = g[1] / ty; a.ntx = g[2] / tx;
+    EXPECT(cm::conv_ups_ok(a, mbw, planes, 1) && cm::conv_ups_ok(a, mbw, planes, 2) && cm::conv_ups_slots(a, mbw) <= MAX_SLOTS);
+    a.C1 = 32;
+    EXPECT(!cm::conv_ups_ok(a, mbw, planes, 1));           // concat sources / normalisation on load stay on the generic kernel
+    a.C1 = 0; a.gn = reinterpret_cast<const float *>(&a);
+    EXPECT(!cm::conv_ups_ok(a, mbw, planes, 1));
+  }
+  {
+    int tz = 0, ty = 0, tx = 0, mbw = 0, planes = 0;
+    EXPECT(cm::conv_ups_pick(4, 6, 18, &tz, &ty, &tx, &mbw, &planes) && tz == 4 && ty == 3 && tx == 9 && mbw == 4 && planes == 1);
+    EXPECT(cm::conv_ups_pick(2, 3, 9, &tz, &ty, &tx, &mbw, &planes) && tz == 2 && ty == 3 && tx == 9 && mbw == 2 && planes == 1);
+  }
   // the whole-sample kernel accepts the quarter resolution of the ATC / CR-120 grids and refuses what it cannot stage
   cm::QrArgs q{};
   q.C0 = 128; q.Co = 128; q.groups = 8; q.Y = 3; q.X = 9;

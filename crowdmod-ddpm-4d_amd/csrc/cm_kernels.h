@@ -94,6 +94,12 @@ int conv_halo_voxels(const ConvArgs &a);
 // MB x NB = number of 32x32 accumulator blocks per wave (workgroup tile 32MB x 32NB).
 hipError_t launch_conv(const ConvArgs &a, int MB, int NB, hipStream_t st);
 bool conv_variant_exists(int MB, int NB);
+// Upsample conv, parity form with the source tile staged once for four parity classes (cm_conv_ups.hip); a.bz / by / bx =
+// the SOURCE tile of conv_ups_pick, nbp = the NB the weights were packed with
+bool conv_ups_pick(int Z, int Y, int X, int *tz, int *ty, int *tx, int *mbw, int *planes);
+bool conv_ups_ok(const ConvArgs &a, int mbw, int planes, int nbp);
+int conv_ups_slots(const ConvArgs &a, int mbw);
+hipError_t launch_conv_ups(const ConvArgs &a, int mbw, int planes, int nbp, hipStream_t st);
 // 3x3x3 conv with <= 8 output channels on the vector ALUs (cm_conv_small.hip); weights packed as
 // [chunk][tap][ci in chunk][NCO = 4 or 8] (internal tap order), zero beyond Co.
 bool conv_smalln_ok(const ConvArgs &a, int MB);

@@ -111,6 +111,8 @@ struct Op {
   long long wpar_stride16 = 0;
   bool f16d = false;        // reduced-precision plan: direct f16-operand kernel (cm_conv_f16.hip) instead of the Winograd one
   int f16d_bz = 0, f16d_by = 0, f16d_bx = 0, f16d_mbw = 0;
+  bool ups = false;         // parity-form upsample conv on the stage-once kernel (cm_conv_ups.hip); source tile + row blocks per wave
+  int ups_tz = 0, ups_ty = 0, ups_tx = 0, ups_mbw = 0, ups_planes = 0;
   float *d_w16d = nullptr, *d_w16d_skip = nullptr;
   bool qr = false;          // whole-sample kernel of the lowest resolution (cm_conv_qr.hip), inference plan
   float *d_wqr = nullptr, *d_wqr_skip = nullptr;
@@ -782,6 +784,10 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   } else {
     wf = pack_conv_weights(wi.data(), (int)w.shape[0], Ci_ref, s.ntaps, Ci_pad, a.CK, op.NB);
   }
+  // upsample convs: the source tile staged once for four parity classes (cm_conv_ups.hip) when a tile fits
+  if (parity && a.CK == 32 && !s.s1 && !s.gn && !s.temb && !s.resid && s.Co % 32 == 0 && s.Co == s.out->C && !cm::diag_env("CM_NO_UPS") &&
+      cm::conv_ups_pick(a.Zs, a.Ys, a.Xs, &op.ups_tz, &op.ups_ty, &op.ups_tx, &op.ups_mbw, &op.ups_planes))
+    op.ups = true;
   // the UNet's last conv (base -> C channels): vector-ALU kernel instead of a 32-wide MFMA tile
   if (s.ntaps == 27 && s.stride == 1 && !s.ups && s.Co <= 8 && !s.stats && !s.temb && !s.resid &&
       !cm::diag_env("CM_NO_SMALLN")) {
@@ -1290,6 +1296,19 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     cb.stat_cnt = op.stat_act->cnt + (size_t)b0 * cb.nslots;
     op.stat_act->nslots = cb.nslots;
     if (run_combine(m, cb, st)) return 1;
+  } else if (op.ups && !(op.d_wfrag16 && !m->train_fwd)) {
+    // upsample conv, fp32: stage-once parity kernel with its own source tile / statistics slots
+    ca.bz = op.ups_tz; ca.by = op.ups_ty; ca.bx = op.ups_tx;
+    ca.ntz = ca.Zs / ca.bz; ca.nty = ca.Ys / ca.by; ca.ntx = ca.Xs / ca.bx;
+    if (op.stat_act) {
+      const int nsu = cm::conv_ups_slots(ca, op.ups_mbw);
+      if (nsu > MAX_SLOTS) return fail("statistics slots %d exceed %d", nsu, MAX_SLOTS);
+      ca.stat_ns = nsu;
+      ca.stat_part = op.stat_act->part + (size_t)b0 * nsu * ca.stat_C * 2;
+      ca.stat_cnt = op.stat_act->cnt + (size_t)b0 * nsu;
+      op.stat_act->nslots = nsu;
+    }
+    CM_HIP(cm::launch_conv_ups(ca, op.ups_mbw, op.ups_planes, op.NB, st));
   } else if (op.wino && op.f16d && !m->train_fwd) {
     // reduced-precision plan: direct f16 kernel with its own tile geometry / statistics slots
     ca.bz = op.f16d_bz; ca.by = op.f16d_by; ca.bx = op.f16d_bx;
@@ -2324,6 +2343,11 @@ int cm_model_exec_flops(const cm_model *m, int32_t B, double flops[8]) {
         f = tiles * ((a.Co + 31) / 32) * 16.0 * 32 * 32 * Ci * 3 * 2;
         if (op.d_s2w) f += tiles * ((a.Co + 31) / 32) * 4.0 * 32 * 32 * (op.skip0->C + (op.skip1 ? op.skip1->C : 0)) * 2;
       }
+    } else if (a.par && op.ups && !(op.d_wfrag16 && m->precision == CM_PRECISION_F16)) {
+      // whole 32-row blocks per (tile, class); planes tiles that span Z skip one of 2 MBW (row block, z tap) pairs
+      const double tiles = (double)(a.Zs / op.ups_tz) * (a.Ys / op.ups_ty) * (a.Xs / op.ups_tx);
+      const double pairs = 2.0 * op.ups_mbw - ((op.ups_planes && op.ups_tz == a.Zs) ? 1.0 : 0.0);
+      f = tiles * 8.0 * 32.0 * pairs * 4.0 * a.Co * Ci * 2;
     } else if (a.par) {
       f = op.flops_per_sample * 8.0 / 27.0;
       if (cm::conv_zsplit_variant(a, op.MB, op.NB)) f *= 6.0 / 8.0;    // two-plane source: 6 of 8 (row block, z tap) pairs
