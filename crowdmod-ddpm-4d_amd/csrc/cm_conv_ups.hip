@@ -322,15 +322,9 @@ static int ups_nb(const ConvArgs &a, int mbw, int nbp) {
   }
   return 1;
 }
-// requested waves per SIMD (= workgroups per CU): every CU should receive the same number of workgroups
-static int ups_occ(int mbw) {
-  if (const char *e = diag_env("CM_UPS_OCC")) {
-    const int v = atoi(e);
-    if (v >= 2 && v <= 4) return v;
-  }
-  (void)mbw;
-  return 2;
-}
+// requested waves per SIMD (= workgroups per CU).  Two: the 4-row-block variant needs 188 registers, and the ATC launches are
+// 1024 / 512 workgroups = whole rounds of two per CU (three or four per CU measured the same or slower: 144.6 / 166.9 us vs 144.4)
+static int ups_occ(int) { return 2; }
 
 bool conv_ups_ok(const ConvArgs &a, int mbw, int planes, int nbp) {
   return a.par == 1 && a.ntaps == 8 && a.td == 2 && a.CK == 32 && a.C1 == 0 && a.C0 % 32 == 0 && a.Co % 32 == 0 && !a.gn && !a.pm && !a.temb &&
@@ -367,7 +361,7 @@ hipError_t launch_conv_ups(const ConvArgs &a_in, int mbw, int planes, int nbp, h
     hipLaunchKernelGGL((conv_ups_kernel<M, N, O>), grid, dim3(256), lds, st, a, tb.tH, tb.tM, tb.HV, tb.ntp, HX, HYX, planes, nbp); \
     return hipGetLastError();                                                                       \
   }
-#define CM_UPS_OCCS(M, N) CM_UPS_GO(M, N, 2) CM_UPS_GO(M, N, 3) CM_UPS_GO(M, N, 4)
+#define CM_UPS_OCCS(M, N) CM_UPS_GO(M, N, 2)
   CM_UPS_OCCS(1, 1) CM_UPS_OCCS(2, 1) CM_UPS_OCCS(3, 1) CM_UPS_OCCS(4, 1) CM_UPS_OCCS(5, 1) CM_UPS_OCCS(2, 2)
 #undef CM_UPS_OCCS
 #undef CM_UPS_GO
