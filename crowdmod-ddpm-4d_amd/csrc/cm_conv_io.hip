@@ -56,21 +56,36 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvArgs a, const
     for (int s = 0; s < NS; ++s) wreg[s] = wp[s * 64];
   }
   // ---- stage the halo image (zero padding outside the grid) ----------------------------
-  for (int hv = tid; hv < HV; hv += 256) {
-    const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
-    const int cz = z0 + hz - 1, cy = y0 + hy - 1, cx = hx - 1;
-    const bool ok = cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs;
-    const float *sp = a.src0 + ((size_t)((b * a.Zs + (ok ? cz : 0)) * a.Ys + (ok ? cy : 0)) * a.Xs + (ok ? cx : 0)) * a.C0;
-    f32x4 v0 = *reinterpret_cast<const f32x4 *>(sp);
-    if (!ok) v0 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (CIN == 4) {
-      *reinterpret_cast<f32x2 *>(P0 + hv * 2) = f32x2{v0[0], v0[1]};
-      *reinterpret_cast<f32x2 *>(P0 + (HV + hv) * 2) = f32x2{v0[2], v0[3]};
-    } else {
-      f32x4 v1 = *reinterpret_cast<const f32x4 *>(sp + 4);
-      if (!ok) v1 = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4 *>(P0 + hv * 4) = v0;
-      *reinterpret_cast<f32x4 *>(P0 + (HV + hv) * 4) = v1;
+  // (four items per pass, loads first: one memory round trip per pass instead of one per item)
+  constexpr int SU = 4;
+  for (int hv0 = tid; hv0 < HV; hv0 += 256 * SU) {
+    f32x4 v0[SU], v1[CIN == 8 ? SU : 1];
+    bool okv[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int hv = min(hv0 + 256 * u, HV - 1);
+      const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+      const int cz = z0 + hz - 1, cy = y0 + hy - 1, cx = hx - 1;
+      const bool ok = cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs;
+      const float *sp = a.src0 + ((size_t)((b * a.Zs + (ok ? cz : 0)) * a.Ys + (ok ? cy : 0)) * a.Xs + (ok ? cx : 0)) * a.C0;
+      v0[u] = *reinterpret_cast<const f32x4 *>(sp);
+      if constexpr (CIN == 8) v1[u] = *reinterpret_cast<const f32x4 *>(sp + 4);
+      okv[u] = ok;
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int hv = hv0 + 256 * u;
+      if (hv >= HV) continue;
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 w0 = okv[u] ? v0[u] : z4;
+      if constexpr (CIN == 4) {
+        *reinterpret_cast<f32x2 *>(P0 + hv * 2) = f32x2{w0[0], w0[1]};
+        *reinterpret_cast<f32x2 *>(P0 + (HV + hv) * 2) = f32x2{w0[2], w0[3]};
+      } else {
+        const f32x4 w1 = okv[u] ? v1[u] : z4;
+        *reinterpret_cast<f32x4 *>(P0 + hv * 4) = w0;
+        *reinterpret_cast<f32x4 *>(P0 + (HV + hv) * 4) = w1;
+      }
     }
   }
   for (int m = tid; m < 32 * nblk; m += 256) {

@@ -94,6 +94,43 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvArgs a, cons
     __syncthreads();
     if constexpr (!WS)
       for (int i = tid; i < 27 * a_CK * NCO; i += 256) W[i] = wsm[(size_t)ch * 27 * a_CK * NCO + i];
+    if constexpr (SPEC) {
+      // all of this thread's halo loads first, then the activations: one memory round trip per chunk instead of one per
+      // item (the loop below issues load -> normalise -> LDS write per item: 7 dependent round trips, ~10 us per workgroup)
+      constexpr int cHV = (BZ + 2) * (BY + 2) * (BX + 2), NI = (cHV * 8 + 255) / 256;
+      const int q = tid & 7;                       // K4 = 8: the channel quad is the same for every item of a thread
+      f32x4 v[NI];
+      unsigned okm = 0;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int hv = (tid >> 3) + 32 * k;
+        const int hp = hvtab_at(hv < cHV ? hv : cHV - 1);
+        const int cx = x0 - 1 + (hp & 511), cy = y0 - 1 + ((hp >> 9) & 511), cz = z0 - 1 + ((hp >> 18) & 255);
+        const bool ok = hv < cHV && cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs;
+        const size_t so = ok ? ((size_t)(b * a.Zs + cz) * a.Ys + cy) * a.Xs + cx : 0;
+        v[k] = *reinterpret_cast<const f32x4 *>(src + so * Cs + c0 + 4 * q);
+        okm |= (ok ? 1u : 0u) << k;
+      }
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, pm = {1.f, 1.f, 1.f, 1.f};
+      if (a.gn) {
+        const float *g = a.gn + (size_t)b * 2 * Ctot + cg0 + 4 * q;
+        sc = *reinterpret_cast<const f32x4 *>(g);
+        sh = *reinterpret_cast<const f32x4 *>(g + Ctot);
+      }
+      if (a.pm) pm = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + cg0 + 4 * q);
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int hv = (tid >> 3) + 32 * k;
+        f32x4 w = v[k];
+        if (a.gn) {
+          w = w * sc + sh;
+          if (a.silu) { w[0] = silu_s(w[0]); w[1] = silu_s(w[1]); w[2] = silu_s(w[2]); w[3] = silu_s(w[3]); }
+        }
+        if (a.pm) w = w * pm;
+        if (!((okm >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hv < cHV) *reinterpret_cast<f32x4 *>(&A[hv * S + 4 * q]) = w;
+      }
+    } else
     for (int i = tid; i < HV * K4; i += 256) {
       const int hv = i / K4, q = i - hv * K4;
       const int hp = hvtab_at(hv);
