@@ -215,3 +215,51 @@ def test_two_lane_loop_with_injected_noise_and_history_equals_b2_loops():
         assert np.array_equal(x2, xB[i:i + 2]), i
         for k in (0, 1, T // 2, T):
             assert np.array_equal(np.asarray(hist2[k]), np.asarray(histB[k])[i:i + 2]), (i, k)
+
+
+_UPS_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from crowdmod_ddpm_4d_amd import spec
+from crowdmod_ddpm_4d_amd.unet import UNet
+from helpers import FULL_GRIDS, SEED_W, full_cfg, synth_inputs
+out = {{}}
+for gname, C_ in (("atc", 4), ("cr120", 3), ("atc2x", 3)):
+    H, W = FULL_GRIDS[gname]
+    cfg = full_cfg(C_)
+    net = UNet(cfg.input_channels, cfg.output_channels, cfg.num_res_blocks, cfg.base_channels, cfg.base_channels_multiples,
+               cfg.apply_attention, cfg.dropout_rate, cfg.time_multiple, "Past", max_batch=8)
+    net.load_state_dict(spec.init_params(cfg, SEED_W))
+    past, fut = synth_inputs(8, C_, H, W, 5, 3, "upsab/" + gname)
+    out[gname] = net(fut, (np.arange(8, dtype=np.int64) * 131 + 7) % 1000, past)
+np.savez({path!r}, **out)
+"""
+
+
+def test_stage_once_upsample_kernel_agrees_with_the_generic_parity_kernel(tmp_path):
+    """cm_conv_ups.hip (source tile staged once for four parity classes; planes tiles skip the padding-plane taps) against
+    the generic parity kernel of cm_conv.hip (selected in a child process with CM_DIAG=1 CM_NO_UPS=1 -- the switch is read
+    once per process): whole-denoiser forwards at B = 8 on all three reference grids (ATC: planes tiles 4x3x9 / 2x3x9;
+    CR-120: planes 4x7x4 and the linear 2x7x6 tile; 24x72: planes 4x3x9, more tiles per sample).  The two kernels sum the
+    same products in a different order (per-wave channel slices reduced at the end vs one running sum), so they agree to
+    fp32 rounding, not bit for bit; both sit within 1e-4 of the reference on the fixture samples (other tests)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    res = {}
+    for tag, extra in (("ups", {}), ("generic", {"CM_DIAG": "1", "CM_NO_UPS": "1"})):
+        path = str(tmp_path / f"{tag}.npz")
+        env = dict(os.environ, **extra)
+        env.pop("CM_CONV_DBG", None)
+        r = subprocess.run([sys.executable, "-c", _UPS_CHILD.format(root=root, tests=here, path=path)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(path)
+    for gname in ("atc", "cr120", "atc2x"):
+        a, b = res["ups"][gname], res["generic"][gname]
+        assert np.isfinite(a).all() and a.shape == b.shape
+        assert not np.array_equal(a, b), "the switch did not change the kernel"
+        assert float(np.abs(a - b).max()) <= 2e-5 * max(1.0, float(np.abs(b).max())), gname
