@@ -31,14 +31,20 @@ namespace cm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // tabH[(p * 2 + pz)][HV]: in-sample source voxel of halo voxel h of tile position p for class p_z, or -1 (zero padding);
 // tabM[p][32 MBW][2]: row m -> halo index of its source voxel at (e = 0, p_y = p_x = 0) | packed global source coordinates
 // (Z << 20 | Y << 10 | X) or -1 (padding row).
-template <int MBW, int NB, int OCC>
+template <int MBW, int NB, int OCC, bool F16 = false>
 __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, const int *__restrict__ tabH, const int *__restrict__ tabM,
                                                          int HV, int ntp, int HX, int HYX, int planes, int NBP) {
-  constexpr int S = 36;                          // LDS row stride in dwords: 32 channels + 4 pad
+  // F16 (reduced-precision plan, cm_model_set_precision): the staged box is rounded to f16 (row = 32 halves + 8 pad halves), the
+  // weights arrive as f16 fragments of 8 halves (pack_ups_f16: one column block per n tile), and a step is ONE
+  // v_mfma_f32_32x32x16_f16 per (row block, column block) over 16 channels -- 16 steps per chunk; fp32 accumulation
+  constexpr int S = F16 ? 20 : 36;               // LDS row stride in dwords: 32 channels + pad
+  constexpr int NST = F16 ? 16 : 32;             // steps per 32-channel chunk
   constexpr int NLD = 10;                        // halo items (voxel, channel quad) per thread and chunk: 8 HV / 256 <= 10 (HV <= 320)
   constexpr int RD = 4;                          // weight ring depth in (tap, channel group) steps; 32 steps per chunk
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -94,16 +100,19 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
 
   // weights of this wave's class: pack_conv_weights order [n tile][chunk][step = tap * 4 + k8][NBP][lane] 16 B
   const int c32 = nt * NB;                        // first 32-channel output block of this workgroup
+  const int nsteps = nch * NST;
+  // fp32: column block nb of a packed n tile sits 64 fragments after nb - 1, a step NBP * 64 after the previous one;
+  // f16:  [column block][step][lane]
+  const int wstep = F16 ? 64 : NBP * 64, wnb = F16 ? nsteps * 64 : 64;
   const f32x4 *wbase = reinterpret_cast<const f32x4 *>(a.wfrag + (size_t)par * a.wpar_stride) +
-                       ((size_t)(c32 / NBP) * nch * 32 * NBP + (c32 % NBP)) * 64 + lane;
-  const int nsteps = nch * 32;
+                       (F16 ? (size_t)c32 * nsteps * 64 : ((size_t)(c32 / NBP) * nch * 32 * NBP + (c32 % NBP)) * 64) + lane;
   f32x4 bw[RD][NB];
 #pragma unroll
   for (int s = 0; s < RD; ++s)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bw[s][nb] = wbase[((size_t)s * NBP + nb) * 64];
-  const f32x4 *wrun = wbase + (size_t)RD * NBP * 64;   // next refill; advanced one step at a time (an address per step, hoisted,
-  const int wstep = NBP * 64;                          //  is 64 registers)
+    for (int nb = 0; nb < NB; ++nb) bw[s][nb] = wbase[(size_t)s * wstep + (size_t)nb * wnb];
+  const f32x4 *wrun = wbase + (size_t)RD * wstep;      // next refill; advanced one step at a time (an address per step, hoisted,
+                                                       //  is 64 registers)
   const int n = nt * 32 * NB + r;                 // (+ 32 nb)
   float bias_pre[NB];
 #pragma unroll
@@ -128,7 +137,12 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
         if (k < nit) {
           const int h = (tid >> 3) + 32 * k;
           const f32x4 w = ((hok >> k) & 1u) ? ld[kk] : f32x4{0.f, 0.f, 0.f, 0.f};
-          if (h < HV) *reinterpret_cast<f32x4 *>(A + (size_t)h * S + 4 * q) = w;
+          if constexpr (F16) {
+            const f16x4 hv = {(_Float16)w[0], (_Float16)w[1], (_Float16)w[2], (_Float16)w[3]};
+            if (h < HV) *reinterpret_cast<f16x4 *>(A + (size_t)h * S + 2 * q) = hv;
+          } else {
+            if (h < HV) *reinterpret_cast<f32x4 *>(A + (size_t)h * S + 4 * q) = w;
+          }
         }
       }
       asm volatile("" ::: "memory");
@@ -140,11 +154,12 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
 #pragma unroll
     for (int j = 0; j < MBW; ++j) afr[0][j] = *reinterpret_cast<const f32x4 *>(A + abase[j]);
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      const int t = s >> 2, ez = t >> 2;
-      if (s + 1 < 32) {
-        const int s1 = s + 1, t1 = s1 >> 2, k81 = s1 & 3;
-        int toff = (((t1 >> 2) * HYX) + ((t1 >> 1) & 1) * HX + (t1 & 1)) * S + 8 * k81;
+    for (int s = 0; s < NST; ++s) {
+      // fp32: step = (tap, 8-channel group k8); f16: step = (tap, 16-channel group)
+      const int t = F16 ? s >> 1 : s >> 2, ez = t >> 2;
+      if (s + 1 < NST) {
+        const int s1 = s + 1, t1 = F16 ? s1 >> 1 : s1 >> 2, kg1 = F16 ? s1 & 1 : s1 & 3;
+        int toff = (((t1 >> 2) * HYX) + ((t1 >> 1) & 1) * HX + (t1 & 1)) * S + 8 * kg1;
         asm volatile("" : "+s"(toff));           // one address add per read, HERE (hoisted, the 32 x MBW sums cost 100+ registers)
 #pragma unroll
         for (int j = 0; j < MBW; ++j) afr[s1 & 1][j] = *reinterpret_cast<const f32x4 *>(A + abase[j] + toff);
@@ -152,19 +167,26 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
 #pragma unroll
       for (int j = 0; j < MBW; ++j) {
         if ((MODE == 1 && j == 0 && ez == 0) || (MODE == 2 && j == MBW - 1 && ez == 1)) continue;   // (compile-time)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+        if constexpr (F16) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s & 1][j][jj], bw[s % RD][nb][jj], acc[j][nb], 0, 0, 0);
+            acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[s & 1][j]), __builtin_bit_cast(f16x8, bw[s % RD][nb]),
+                                                                acc[j][nb], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s & 1][j][jj], bw[s % RD][nb][jj], acc[j][nb], 0, 0, 0);
+        }
       }
       // refill this ring slot AFTER the matrix instructions that read it; the fence keeps the request here (hipcc would
       // sink it to its first use, and every step would pay an L2 round trip)
       {
-        const int g = ch * 32 + s + RD;
+        const int g = ch * NST + s + RD;
         if (g < nsteps) {
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) bw[s % RD][nb] = wrun[nb * 64];
+          for (int nb = 0; nb < NB; ++nb) bw[s % RD][nb] = wrun[(size_t)nb * wnb];
         }
         wrun += wstep;
         asm volatile("" : "+v"(wrun));
@@ -313,7 +335,7 @@ static hipError_t ups_tabs_get(const ConvArgs &a, int mbw, int planes, UpsTabs *
 }
 
 // `a` describes the parity-form conv as cm_model.cpp builds it (par = 1, ntaps = 8, CK = 32, weights packed with NB = nbp);
-// a.bz / by / bx here = the SOURCE tile of conv_ups_pick
+// a.bz / by / bx here = the SOURCE tile of conv_ups_pick.  a.f16: wfrag holds pack_ups_f16 fragments (nbp ignored)
 // 32-channel column blocks per workgroup: one (more, smaller workgroups hide each other's staging and epilogue)
 static int ups_nb(const ConvArgs &a, int mbw, int nbp) {
   if (const char *e = diag_env("CM_UPS_NB")) {
@@ -328,7 +350,7 @@ static int ups_occ(int) { return 2; }
 
 bool conv_ups_ok(const ConvArgs &a, int mbw, int planes, int nbp) {
   return a.par == 1 && a.ntaps == 8 && a.td == 2 && a.CK == 32 && a.C1 == 0 && a.C0 % 32 == 0 && a.Co % 32 == 0 && !a.gn && !a.pm && !a.temb &&
-         !a.resid && !a.s2w && a.ks <= 1 && !a.f16 && a.Zo == 2 * a.Zs && a.Yo == 2 * a.Ys && a.Xo == 2 * a.Xs && mbw >= 1 && mbw <= 5 &&
+         !a.resid && !a.s2w && a.ks <= 1 && a.Zo == 2 * a.Zs && a.Yo == 2 * a.Ys && a.Xo == 2 * a.Xs && mbw >= 1 && mbw <= 5 &&
          a.bz > 0 && a.by > 0 && a.bx > 0 && a.Zs % a.bz == 0 && a.Ys % a.by == 0 && a.Xs % a.bx == 0 &&
          (a.bz + 1) * (a.by + 2) * (a.bx + 2) <= 320 && (planes ? (a.by * a.bx <= 32 && a.bz == mbw) : a.bz * a.by * a.bx <= 32 * mbw) &&
          (nbp == 1 || nbp == 2) &&
@@ -345,23 +367,23 @@ hipError_t launch_conv_ups(const ConvArgs &a_in, int mbw, int planes, int nbp, h
   hipError_t et = ups_tabs_get(a, mbw, planes, &tb);
   if (et != hipSuccess) return et;
   const int nb = ups_nb(a, mbw, nbp), occ = ups_occ(mbw);   // (a workgroup's NB column blocks sit in one packed n tile)
-  const size_t lds = (size_t)tb.HV * 36 * sizeof(float);
+  const size_t lds = (size_t)tb.HV * (a.f16 ? 20 : 36) * sizeof(float);
   const dim3 grid((unsigned)(a.B * tb.ntp), (unsigned)(a.Co / (32 * nb)), 2);
   const int HX = a.bx + 2, HYX = (a.by + 2) * HX;
-#define CM_UPS_GO(M, N, O)                                                                          \
-  if (mbw == M && nb == N && occ == O) {                                                            \
+#define CM_UPS_GO(M, N, O, H)                                                                       \
+  if (mbw == M && nb == N && occ == O && (a.f16 != 0) == H) {                                       \
     static bool attr_set[64] = {false};                                                             \
     int dev = 0;                                                                                    \
     (void)hipGetDevice(&dev);                                                                       \
     if (!attr_set[dev & 63]) {                                                                      \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_ups_kernel<M, N, O>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_ups_kernel<M, N, O, H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       if (e != hipSuccess) return e;                                                                \
       attr_set[dev & 63] = true;                                                                    \
     }                                                                                               \
-    hipLaunchKernelGGL((conv_ups_kernel<M, N, O>), grid, dim3(256), lds, st, a, tb.tH, tb.tM, tb.HV, tb.ntp, HX, HYX, planes, nbp); \
+    hipLaunchKernelGGL((conv_ups_kernel<M, N, O, H>), grid, dim3(256), lds, st, a, tb.tH, tb.tM, tb.HV, tb.ntp, HX, HYX, planes, nbp); \
     return hipGetLastError();                                                                       \
   }
-#define CM_UPS_OCCS(M, N) CM_UPS_GO(M, N, 2)
+#define CM_UPS_OCCS(M, N) CM_UPS_GO(M, N, 2, false) CM_UPS_GO(M, N, 2, true)
   CM_UPS_OCCS(1, 1) CM_UPS_OCCS(2, 1) CM_UPS_OCCS(3, 1) CM_UPS_OCCS(4, 1) CM_UPS_OCCS(5, 1) CM_UPS_OCCS(2, 2)
 #undef CM_UPS_OCCS
 #undef CM_UPS_GO

@@ -227,6 +227,20 @@ void test_round3_packers() {
           EXPECT(h[o] == f32_to_f16_bits(wi[((size_t)co * Ci + ci) * 27 + t]));
         }
       }
+      // pack_ups_f16 (one parity class, [Co][Ci][8]): [column block][chunk][tap][16-channel group][lane][8]
+      if (Ci % 32 == 0) {
+        std::vector<float> w8((size_t)Co * Ci * 8);
+        for (auto &v : w8) v = U(rng);
+        const std::vector<float> f = pack_ups_f16(w8.data(), Co, Ci);
+        EXPECT(f.size() * 2 == w8.size());
+        const uint16_t *h = reinterpret_cast<const uint16_t *>(f.data());
+        for (int probe = 0; probe < 100; ++probe) {
+          const int co = (int)(rng() % Co), ci = (int)(rng() % Ci), t = (int)(rng() % 8);
+          const int cbk = co / 32, ch = ci / 32, mg = (ci % 32) / 16, lane = 32 * ((ci % 16) / 8) + co % 32, i = ci % 8;
+          const size_t o = ((((((size_t)cbk * (Ci / 32) + ch) * 8 + t) * 2 + mg) * 64) + lane) * 8 + i;
+          EXPECT(h[o] == f32_to_f16_bits(w8[((size_t)co * Ci + ci) * 8 + t]));
+        }
+      }
     }
   // tile planner of the direct f16 kernel: every reference grid level gets a tile that divides it and fits the kernel's limits
   const int grids[][3] = {{8, 12, 36}, {4, 6, 18}, {8, 28, 24}, {4, 14, 12}, {8, 24, 72}, {4, 12, 36}};

@@ -113,6 +113,8 @@ struct Op {
   int f16d_bz = 0, f16d_by = 0, f16d_bx = 0, f16d_mbw = 0;
   bool ups = false;         // parity-form upsample conv on the stage-once kernel (cm_conv_ups.hip); source tile + row blocks per wave
   int ups_tz = 0, ups_ty = 0, ups_tx = 0, ups_mbw = 0, ups_planes = 0;
+  float *d_wups16 = nullptr;    // its f16 fragments under the reduced-precision plan (pack_ups_f16), floats per parity class
+  long long wups16_stride = 0;
   float *d_w16d = nullptr, *d_w16d_skip = nullptr;
   bool qr = false;          // whole-sample kernel of the lowest resolution (cm_conv_qr.hip), inference plan
   float *d_wqr = nullptr, *d_wqr_skip = nullptr;
@@ -417,6 +419,27 @@ std::vector<float> pack_conv_weights_f16(const float *W, int Co, int Ci, int nta
               if (co < Co && ci < Ci) out[o] = f32_to_f16_bits(W[((size_t)co * Ci + ci) * ntaps + t]);
             }
       }
+  std::vector<float> packed(out.size() / 2);
+  std::memcpy(packed.data(), out.data(), out.size() * 2);
+  return packed;
+}
+
+// f16 fragments of ONE parity class for the stage-once upsample kernel (cm_conv_ups.hip, F16): [32-channel column block]
+// [32-channel chunk][tap 8][16-channel group m][lane][8 halves], lane = 32 hh + (co % 32), ci = chunk * 32 + 16 m + 8 hh + i.
+// W: [Co][Ci][8] (parity_weights of one class).  Returned as floats holding two halves each.
+std::vector<float> pack_ups_f16(const float *W, int Co, int Ci) {
+  const int ncb = Co / 32, nch = Ci / 32;
+  std::vector<uint16_t> out((size_t)ncb * nch * 8 * 2 * 64 * 8, 0);
+  size_t o = 0;
+  for (int cb = 0; cb < ncb; ++cb)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int t = 0; t < 8; ++t)
+        for (int mg = 0; mg < 2; ++mg)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int i = 0; i < 8; ++i, ++o) {
+              const int co = cb * 32 + (lane & 31), ci = ch * 32 + 16 * mg + 8 * (lane >> 5) + i;
+              out[o] = f32_to_f16_bits(W[((size_t)co * Ci + ci) * 8 + t]);
+            }
   std::vector<float> packed(out.size() / 2);
   std::memcpy(packed.data(), out.data(), out.size() * 2);
   return packed;
@@ -788,6 +811,17 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   if (parity && a.CK == 32 && !s.s1 && !s.gn && !s.temb && !s.resid && s.Co % 32 == 0 && s.Co == s.out->C && !cm::diag_env("CM_NO_UPS") &&
       cm::conv_ups_pick(a.Zs, a.Ys, a.Xs, &op.ups_tz, &op.ups_ty, &op.ups_tx, &op.ups_mbw, &op.ups_planes))
     op.ups = true;
+  if (op.ups && m->precision == CM_PRECISION_F16 && Ci_ref == Ci_pad && Ci_ref % 32 == 0 && !cm::diag_env("CM_NO_UPS_F16")) {
+    const std::vector<float> wp = parity_weights(wi, (int)w.shape[0], Ci_ref);
+    const size_t per = (size_t)w.shape[0] * Ci_ref * 8;
+    std::vector<float> w16;
+    for (int p8 = 0; p8 < 8; ++p8) {
+      const std::vector<float> one = pack_ups_f16(wp.data() + p8 * per, (int)w.shape[0], Ci_ref);
+      op.wups16_stride = (long long)one.size();
+      w16.insert(w16.end(), one.begin(), one.end());
+    }
+    if (upload(m, w16, &op.d_wups16)) return 1;
+  }
   // the UNet's last conv (base -> C channels): vector-ALU kernel instead of a 32-wide MFMA tile
   if (s.ntaps == 27 && s.stride == 1 && !s.ups && s.Co <= 8 && !s.stats && !s.temb && !s.resid &&
       !cm::diag_env("CM_NO_SMALLN")) {
@@ -1296,8 +1330,10 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     cb.stat_cnt = op.stat_act->cnt + (size_t)b0 * cb.nslots;
     op.stat_act->nslots = cb.nslots;
     if (run_combine(m, cb, st)) return 1;
-  } else if (op.ups && !(op.d_wfrag16 && !m->train_fwd)) {
-    // upsample conv, fp32: stage-once parity kernel with its own source tile / statistics slots
+  } else if (op.ups && (op.d_wups16 || !(op.d_wfrag16 && !m->train_fwd))) {
+    // upsample conv: stage-once parity kernel with its own source tile / statistics slots (f16 operands under the
+    // reduced-precision plan's inference forward)
+    if (op.d_wups16 && !m->train_fwd) { ca.wfrag = op.d_wups16; ca.wpar_stride = op.wups16_stride; ca.f16 = 1; }
     ca.bz = op.ups_tz; ca.by = op.ups_ty; ca.bx = op.ups_tx;
     ca.ntz = ca.Zs / ca.bz; ca.nty = ca.Ys / ca.by; ca.ntx = ca.Xs / ca.bx;
     if (op.stat_act) {
@@ -2343,7 +2379,7 @@ int cm_model_exec_flops(const cm_model *m, int32_t B, double flops[8]) {
         f = tiles * ((a.Co + 31) / 32) * 16.0 * 32 * 32 * Ci * 3 * 2;
         if (op.d_s2w) f += tiles * ((a.Co + 31) / 32) * 4.0 * 32 * 32 * (op.skip0->C + (op.skip1 ? op.skip1->C : 0)) * 2;
       }
-    } else if (a.par && op.ups && !(op.d_wfrag16 && m->precision == CM_PRECISION_F16)) {
+    } else if (a.par && op.ups && (op.d_wups16 || !(op.d_wfrag16 && m->precision == CM_PRECISION_F16))) {
       // whole 32-row blocks per (tile, class); planes tiles that span Z skip one of 2 MBW (row block, z tap) pairs
       const double tiles = (double)(a.Zs / op.ups_tz) * (a.Ys / op.ups_ty) * (a.Xs / op.ups_tx);
       const double pairs = 2.0 * op.ups_mbw - ((op.ups_planes && op.ups_tz == a.Zs) ? 1.0 : 0.0);
