@@ -315,9 +315,10 @@ def main():
         exe = conv3_exec / conv_s / 1e12 if conv_s > 0 else 0.0
         peak = FP32_MFMA_PEAK_TFLOPS if a.dtype == "f32" else F16_MFMA_PEAK_TFLOPS
         roofline = {
-            "kernel": "all 3x3x3 conv launches: conv_wino_kernel (Winograd F(2x2,3x3) over the in-plane axes, full- and "
-                      "half-resolution layers), conv_mfma_kernel<*,*,27|8> (direct / parity-form upsample / stride 2 / "
-                      "K-split quarter resolution), conv_first_kernel, conv_smalln_kernel",
+            "kernel": "all 3x3x3 conv launches: conv_wino[_p]_kernel (Winograd F(2x2,3x3) over the in-plane axes, full- and "
+                      "half-resolution layers), conv_qr2_kernel (whole-sample quarter resolution), conv_ups_kernel (parity-form "
+                      "upsample convs, source tile staged once), conv_mfma_kernel<*,*,27> (stride 2), conv_first_kernel, "
+                      "conv_smalln_kernel",
             "bound": "mfma", "achieved": exe, "peak": peak, "unit": "TFLOP/s",
             "frac": exe / peak, "traffic": hbm_traffic(),
             "algorithmic_tflops": ach, "algorithmic_frac": ach / peak,

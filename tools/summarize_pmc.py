@@ -49,7 +49,7 @@ for k in sorted(fetch, key=lambda k: -sum(fetch[k]["FETCH_SIZE"])):
     lds_conf = tot("SQ_LDS_BANK_CONFLICT") / max(1.0, tot("SQ_LDS_IDX_ACTIVE")) if s else float("nan")
     rows.append((k, n, fk, wk, hbm, mfma_busy, valu_per_mfma, lds_conf))
     m3 = re.search(r"conv_mfma_kernel<\d+, \d+, (\d+)", k)
-    if (m3 and m3.group(1) in ("27", "127", "8", "327", "427", "308")) or any(t in k for t in ("conv_smalln", "conv_wino", "conv_qr", "conv_f16d", "conv_first_kernel")):
+    if (m3 and m3.group(1) in ("27", "127", "8", "327", "427", "308")) or any(t in k for t in ("conv_smalln", "conv_wino", "conv_qr", "conv_f16d", "conv_ups", "conv_first_kernel")):
         conv_bytes += hbm * n
         conv_n += n
 with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.csv"), "w") as fo:
@@ -60,7 +60,7 @@ with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.csv"), "w") as fo:
 sys.path.insert(0, ROOT)
 from bench import csrc_sha16  # noqa: E402  (fingerprint of the kernel sources this measurement belongs to)
 json.dump({
-    "kernel_class": "conv_wino[_p]_kernel + conv_qr[2]_kernel + conv_mfma_kernel<*,*,27|127|327|427|8|308> + conv_first_kernel + conv_smalln_kernel (all 3x3x3 conv launches)",
+    "kernel_class": "conv_wino[_p]_kernel + conv_qr[2]_kernel + conv_ups_kernel + conv_mfma_kernel<*,*,27|127|327|427|8|308> + conv_first_kernel + conv_smalln_kernel (all 3x3x3 conv launches)",
     "csrc_sha16": csrc_sha16(),
     "hbm_bytes_per_launch": conv_bytes / max(1, conv_n),
     "launches_counted": conv_n,
