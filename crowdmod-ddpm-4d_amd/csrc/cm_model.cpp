@@ -809,7 +809,8 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   }
   // upsample convs: the source tile staged once for four parity classes (cm_conv_ups.hip) when a tile fits
   if (parity && a.CK == 32 && !s.s1 && !s.gn && !s.temb && !s.resid && s.Co % 32 == 0 && s.Co == s.out->C && !cm::diag_env("CM_NO_UPS") &&
-      cm::conv_ups_pick(a.Zs, a.Ys, a.Xs, &op.ups_tz, &op.ups_ty, &op.ups_tx, &op.ups_mbw, &op.ups_planes))
+      cm::conv_ups_pick(a.Zs, a.Ys, a.Xs, &op.ups_tz, &op.ups_ty, &op.ups_tx, &op.ups_mbw, &op.ups_planes) &&
+      (a.Zs / op.ups_tz) * (a.Ys / op.ups_ty) * (a.Xs / op.ups_tx) * 8 * op.ups_mbw <= MAX_SLOTS)   // (its statistics slots must fit)
     op.ups = true;
   if (op.ups && m->precision == CM_PRECISION_F16 && Ci_ref == Ci_pad && Ci_ref % 32 == 0 && !cm::diag_env("CM_NO_UPS_F16")) {
     const std::vector<float> wp = parity_weights(wi, (int)w.shape[0], Ci_ref);
