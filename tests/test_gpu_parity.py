@@ -483,6 +483,32 @@ def test_frame_metrics_vs_reference_tables():
 
 
 @pytest.mark.gpu
+def test_metric_dispatch_all_and_motion_feature_tables_through_the_generator(tmp_path):
+    """compute_metrics (metricsGenerator.py:379-395) on the MetricsGenerator that owns the device reductions: 'ALL' fills the
+    PSNR / SSIM / motion-feature / density / TV tables (never ENERGY: the reference lists it under 'ALLA'), the motion-feature
+    tables equal the reference's (tests/golden/motion_feat.npz), both spellings of the Bhattacharyya metric select it, the CSV
+    writer emits the reference's column headers, and an unknown metric is a ValueError."""
+    from crowdmod_ddpm_4d_amd.metrics import MetricsGenerator, compute_metrics
+    g = load("motion_feat.npz")
+    mf = {"f": int(g["atc/fkg"][0]), "k": int(g["atc/fkg"][1]), "GAMMA": float(g["atc/fkg"][2])}
+    mg = compute_metrics(MetricsGenerator(g["pred"], g["gt"], 3), "ALL", 2, 1e-8, motion_feature=mf)
+    for k in ("PSNR", "MASK_PSNR", "SSIM", "MF_MSE", "MF_BHATT_DIST", "MF_BHATT_COEF", "RE_DENSITY", "TV_OVER_TIME"):
+        assert mg.data_dict.get(k) is not None, k
+    assert "ENERGY" not in mg.data_dict
+    for k in ("MF_MSE", "MF_BHATT_DIST", "MF_BHATT_COEF"):
+        np.testing.assert_allclose(mg.data_dict[k], g[f"atc/{k}"], rtol=1e-10, atol=1e-15, err_msg=k)
+    for name in ("MF_BHATT", "MOTION_FEAT_BHATT"):
+        one = compute_metrics(MetricsGenerator(g["pred"], g["gt"], 3), name, 2, 1e-8, motion_feature=mf)
+        assert one.data_dict["MF_MSE"] is None and "PSNR" not in one.data_dict
+        np.testing.assert_allclose(one.data_dict["MF_BHATT_COEF"], g["atc/MF_BHATT_COEF"], rtol=1e-10)
+    index = mg.save_data_metrics(str(tmp_path), "t", 6)
+    assert open(index["MF_BHATT_DIST"]).readline().strip() == "BHATT_DIST_Hist_2D_Based,BHATT_DIST_Hist_1D_Based"
+    assert open(index["MF_MSE"]).readline().strip() == "MSE_Hist_2D_Based,MSE_Hist_1D_Based"
+    with pytest.raises(ValueError):
+        compute_metrics(mg, "MF_COSINE", 2, 1e-8)
+
+
+@pytest.mark.gpu
 def test_training_backward_full_width_model_vs_reference():
     """The same training step on the FULL-width model (base 32, ATC 12x36, B = 2): the 32-channel-chunk register-ring
     kernels, K-split quarter-resolution layers, parity-form upsample convs and 128-wide attention of the backward
