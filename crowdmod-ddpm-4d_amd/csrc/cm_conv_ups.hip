@@ -33,20 +33,30 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // tabH[(p * 2 + pz)][HV]: in-sample source voxel of halo voxel h of tile position p for class p_z, or -1 (zero padding);
 // tabM[p][32 MBW][2]: row m -> halo index of its source voxel at (e = 0, p_y = p_x = 0) | packed global source coordinates
 // (Z << 20 | Y << 10 | X) or -1 (padding row).
-template <int MBW, int NB, int OCC, bool F16 = false>
+template <int MBW, int NB, int OCC, int PREC = 0>
 __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, const int *__restrict__ tabH, const int *__restrict__ tabM,
                                                          int HV, int ntp, int HX, int HYX, int planes, int NBP) {
   // F16 (reduced-precision plan, cm_model_set_precision): the staged box is rounded to f16 (row = 32 halves + 8 pad halves), the
   // weights arrive as f16 fragments of 8 halves (pack_ups_f16: one column block per n tile), and a step is ONE
   // v_mfma_f32_32x32x16_f16 per (row block, column block) over 16 channels -- 16 steps per chunk; fp32 accumulation
-  constexpr int S = F16 ? 20 : 36;               // LDS row stride in dwords: 32 channels + pad
-  constexpr int NST = F16 ? 16 : 32;             // steps per 32-channel chunk
+  // PREC = 2 (B6): fp32 products formed on the bf16 matrix instruction from exact three-way splits x = hi + mid + lo
+  // (8 + 8 + 8 mantissa bits: the split loses nothing).  Six cross terms per product -- hi*lo, lo*hi, mid*mid, hi*mid, mid*hi,
+  // hi*hi; the three dropped ones are <= 2^-24 of the product -- accumulate in fp32: the error against an fp64 reference is
+  // that of the fp32 instruction (simulation in DESIGN section 6: rms 2.7e-7 vs 3.3e-7 of the k-ordered fp32 chain at K = 512),
+  // and 16 channels take 6 x 32 cycles instead of 8 x 64.  The staged box is split once per voxel at the LDS write (three
+  // bf16 planes per row), the weights arrive pre-split (pack_ups_b6).
+  constexpr bool F16 = PREC == 1, B6 = PREC == 2;
+  constexpr int NTM = B6 ? 3 : 1;                // operand terms
+  constexpr int S = B6 ? 52 : (F16 ? 20 : 36);   // LDS row stride in dwords: 32 channels (x 3 bf16 planes) + pad
+  constexpr int NST = PREC ? 16 : 32;            // steps per 32-channel chunk
   constexpr int NLD = 10;                        // halo items (voxel, channel quad) per thread and chunk: 8 HV / 256 <= 10 (HV <= 320)
-  constexpr int RD = 4;                          // weight ring depth in (tap, channel group) steps; 32 steps per chunk
+  constexpr int RD = B6 ? 2 : 4;                 // weight ring depth in (tap, channel group) steps; NST % RD == 0
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *A = lds;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -102,15 +112,17 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
   const int c32 = nt * NB;                        // first 32-channel output block of this workgroup
   const int nsteps = nch * NST;
   // fp32: column block nb of a packed n tile sits 64 fragments after nb - 1, a step NBP * 64 after the previous one;
-  // f16:  [column block][step][lane]
-  const int wstep = F16 ? 64 : NBP * 64, wnb = F16 ? nsteps * 64 : 64;
+  // f16 / B6:  [column block][step][term][lane]
+  const int wstep = PREC ? NTM * 64 : NBP * 64, wnb = PREC ? nsteps * NTM * 64 : 64;
   const f32x4 *wbase = reinterpret_cast<const f32x4 *>(a.wfrag + (size_t)par * a.wpar_stride) +
-                       (F16 ? (size_t)c32 * nsteps * 64 : ((size_t)(c32 / NBP) * nch * 32 * NBP + (c32 % NBP)) * 64) + lane;
-  f32x4 bw[RD][NB];
+                       (PREC ? (size_t)c32 * nsteps * NTM * 64 : ((size_t)(c32 / NBP) * nch * 32 * NBP + (c32 % NBP)) * 64) + lane;
+  f32x4 bw[RD][NTM][NB];
 #pragma unroll
   for (int s = 0; s < RD; ++s)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bw[s][nb] = wbase[(size_t)s * wstep + (size_t)nb * wnb];
+    for (int tm = 0; tm < NTM; ++tm)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bw[s][tm][nb] = wbase[(size_t)s * wstep + (size_t)tm * 64 + (size_t)nb * wnb];
   const f32x4 *wrun = wbase + (size_t)RD * wstep;      // next refill; advanced one step at a time (an address per step, hoisted,
                                                        //  is 64 registers)
   const int n = nt * 32 * NB + r;                 // (+ 32 nb)
@@ -137,7 +149,19 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
         if (k < nit) {
           const int h = (tid >> 3) + 32 * k;
           const f32x4 w = ((hok >> k) & 1u) ? ld[kk] : f32x4{0.f, 0.f, 0.f, 0.f};
-          if constexpr (F16) {
+          if constexpr (B6) {
+            bf16x4 t3[3];
+            f32x4 rem = w;
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) {
+              t3[tm] = bf16x4{(__bf16)rem[0], (__bf16)rem[1], (__bf16)rem[2], (__bf16)rem[3]};
+              if (tm < 2) rem = rem - f32x4{(float)t3[tm][0], (float)t3[tm][1], (float)t3[tm][2], (float)t3[tm][3]};   // exact
+            }
+            if (h < HV) {
+#pragma unroll
+              for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<bf16x4 *>(A + (size_t)h * S + 16 * tm + 2 * q) = t3[tm];
+            }
+          } else if constexpr (F16) {
             const f16x4 hv = {(_Float16)w[0], (_Float16)w[1], (_Float16)w[2], (_Float16)w[3]};
             if (h < HV) *reinterpret_cast<f16x4 *>(A + (size_t)h * S + 2 * q) = hv;
           } else {
@@ -150,34 +174,47 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
     __syncthreads();
     if (a.dbg & 2) continue;
     // ---- matrix phase: 8 taps x 4 channel groups ----------------------------------------------------------------------
-    f32x4 afr[2][MBW];
+    f32x4 afr[2][NTM][MBW];
 #pragma unroll
-    for (int j = 0; j < MBW; ++j) afr[0][j] = *reinterpret_cast<const f32x4 *>(A + abase[j]);
+    for (int tm = 0; tm < NTM; ++tm)
+#pragma unroll
+      for (int j = 0; j < MBW; ++j) afr[0][tm][j] = *reinterpret_cast<const f32x4 *>(A + abase[j] + 16 * tm);
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
-      // fp32: step = (tap, 8-channel group k8); f16: step = (tap, 16-channel group)
-      const int t = F16 ? s >> 1 : s >> 2, ez = t >> 2;
+      // fp32: step = (tap, 8-channel group k8); f16 / B6: step = (tap, 16-channel group)
+      const int t = PREC ? s >> 1 : s >> 2, ez = t >> 2;
       if (s + 1 < NST) {
-        const int s1 = s + 1, t1 = F16 ? s1 >> 1 : s1 >> 2, kg1 = F16 ? s1 & 1 : s1 & 3;
+        const int s1 = s + 1, t1 = PREC ? s1 >> 1 : s1 >> 2, kg1 = PREC ? s1 & 1 : s1 & 3;
         int toff = (((t1 >> 2) * HYX) + ((t1 >> 1) & 1) * HX + (t1 & 1)) * S + 8 * kg1;
         asm volatile("" : "+s"(toff));           // one address add per read, HERE (hoisted, the 32 x MBW sums cost 100+ registers)
 #pragma unroll
-        for (int j = 0; j < MBW; ++j) afr[s1 & 1][j] = *reinterpret_cast<const f32x4 *>(A + abase[j] + toff);
+        for (int tm = 0; tm < NTM; ++tm)
+#pragma unroll
+          for (int j = 0; j < MBW; ++j) afr[s1 & 1][tm][j] = *reinterpret_cast<const f32x4 *>(A + abase[j] + toff + 16 * tm);
       }
 #pragma unroll
       for (int j = 0; j < MBW; ++j) {
         if ((MODE == 1 && j == 0 && ez == 0) || (MODE == 2 && j == MBW - 1 && ez == 1)) continue;   // (compile-time)
-        if constexpr (F16) {
+        if constexpr (B6) {
+          // (A term, B term), small products first: hi = 0, mid = 1, lo = 2
+          constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[s & 1][j]), __builtin_bit_cast(f16x8, bw[s % RD][nb]),
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+              acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[s & 1][TA[u]][j]),
+                                                                   __builtin_bit_cast(bf16x8, bw[s % RD][TB[u]][nb]), acc[j][nb], 0, 0, 0);
+        } else if constexpr (F16) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[s & 1][0][j]), __builtin_bit_cast(f16x8, bw[s % RD][0][nb]),
                                                                 acc[j][nb], 0, 0, 0);
         } else {
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-              acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s & 1][j][jj], bw[s % RD][nb][jj], acc[j][nb], 0, 0, 0);
+              acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s & 1][0][j][jj], bw[s % RD][0][nb][jj], acc[j][nb], 0, 0, 0);
         }
       }
       // refill this ring slot AFTER the matrix instructions that read it; the fence keeps the request here (hipcc would
@@ -186,7 +223,9 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
         const int g = ch * NST + s + RD;
         if (g < nsteps) {
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) bw[s % RD][nb] = wrun[(size_t)nb * wnb];
+          for (int tm = 0; tm < NTM; ++tm)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bw[s % RD][tm][nb] = wrun[(size_t)tm * 64 + (size_t)nb * wnb];
         }
         wrun += wstep;
         asm volatile("" : "+v"(wrun));
@@ -244,6 +283,42 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
   if (mode == 0) body(std::integral_constant<int, 0>{});
   else if (mode == 1) body(std::integral_constant<int, 1>{});
   else body(std::integral_constant<int, 2>{});
+}
+
+// After an optimizer step the fp32 parity fragments (pack_conv_weights order, re-derived on the device by gather_pack) are the
+// source of truth: split them again into the hi / mid / lo planes of pack_ups_b6.  One thread per (class, co, ci, tap).
+__global__ __launch_bounds__(256) void ups_b6_repack_kernel(const float *__restrict__ wf, long long wpar_stride, unsigned short *__restrict__ w6,
+                                                            long long w6_stride_halves, int Co, int Ci, int NBP) {
+  const long long n = 8LL * Co * Ci * 8, i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int t = (int)(i & 7);
+  long long q = i >> 3;
+  const int ci = (int)(q % Ci); q /= Ci;
+  const int co = (int)(q % Co);
+  const int par = (int)(q / Co);
+  const int nch = Ci >> 5, ch = ci >> 5, cl = ci & 31;
+  // source: [n tile][chunk][step = tap * 4 + k8][NBP][lane][4], ci = chunk * 32 + 8 k8 + 4 hh + jj, co = (n tile * NBP + nb) * 32 + r
+  const int c32 = co >> 5, r = co & 31, k8 = cl >> 3, hs = (cl >> 2) & 1, jj = cl & 3;
+  const float w = wf[(size_t)par * wpar_stride +
+                     ((((size_t)(c32 / NBP) * nch + ch) * 32 + t * 4 + k8) * NBP + (c32 % NBP)) * 256 + (32 * hs + r) * 4 + jj];
+  // destination: [column block][chunk][tap][m][term][lane][8], ci = chunk * 32 + 16 m + 8 hh + e
+  const int mg = cl >> 4, hd = (cl >> 3) & 1, e = cl & 7;
+  unsigned short *dst = w6 + (size_t)par * w6_stride_halves + ((((((size_t)c32 * nch + ch) * 8 + t) * 2 + mg) * 3) * 64 + 32 * hd + r) * 8 + e;
+  float rem = w;
+#pragma unroll
+  for (int tm = 0; tm < 3; ++tm) {
+    const __bf16 hb = (__bf16)rem;
+    dst[(size_t)tm * 64 * 8] = __builtin_bit_cast(unsigned short, hb);
+    rem -= (float)hb;
+  }
+}
+
+hipError_t launch_ups_b6_repack(const float *wfrag, long long wpar_stride, float *w6, long long w6_stride, int Co, int Ci, int NBP, hipStream_t st) {
+  if (Co % 32 || Ci % 32 || (NBP != 1 && NBP != 2)) return hipErrorInvalidValue;
+  const long long n = 8LL * Co * Ci * 8;
+  hipLaunchKernelGGL(ups_b6_repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wfrag, wpar_stride,
+                     reinterpret_cast<unsigned short *>(w6), w6_stride * 2, Co, Ci, NBP);
+  return hipGetLastError();
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -335,12 +410,12 @@ static hipError_t ups_tabs_get(const ConvArgs &a, int mbw, int planes, UpsTabs *
 }
 
 // `a` describes the parity-form conv as cm_model.cpp builds it (par = 1, ntaps = 8, CK = 32, weights packed with NB = nbp);
-// a.bz / by / bx here = the SOURCE tile of conv_ups_pick.  a.f16: wfrag holds pack_ups_f16 fragments (nbp ignored)
+// a.bz / by / bx here = the SOURCE tile of conv_ups_pick.  a.f16 = 1: wfrag holds pack_ups_f16 fragments, 2: pack_ups_b6 (nbp ignored)
 // 32-channel column blocks per workgroup: one (more, smaller workgroups hide each other's staging and epilogue)
 static int ups_nb(const ConvArgs &a, int mbw, int nbp) {
   if (const char *e = diag_env("CM_UPS_NB")) {
     const int v = atoi(e);
-    if (v == 2 && mbw <= 2 && nbp == 2 && a.Co % 64 == 0) return 2;
+    if (v == 2 && mbw <= 2 && (nbp == 2 || a.f16) && a.Co % 64 == 0) return 2;
   }
   return 1;
 }
@@ -367,11 +442,12 @@ hipError_t launch_conv_ups(const ConvArgs &a_in, int mbw, int planes, int nbp, h
   hipError_t et = ups_tabs_get(a, mbw, planes, &tb);
   if (et != hipSuccess) return et;
   const int nb = ups_nb(a, mbw, nbp), occ = ups_occ(mbw);   // (a workgroup's NB column blocks sit in one packed n tile)
-  const size_t lds = (size_t)tb.HV * (a.f16 ? 20 : 36) * sizeof(float);
+  const int prec = a.f16;                          // 0: fp32 matrix instruction, 1: f16 operands, 2: bf16 x 6 split products
+  const size_t lds = (size_t)tb.HV * (prec == 2 ? 52 : (prec == 1 ? 20 : 36)) * sizeof(float);
   const dim3 grid((unsigned)(a.B * tb.ntp), (unsigned)(a.Co / (32 * nb)), 2);
   const int HX = a.bx + 2, HYX = (a.by + 2) * HX;
 #define CM_UPS_GO(M, N, O, H)                                                                       \
-  if (mbw == M && nb == N && occ == O && (a.f16 != 0) == H) {                                       \
+  if (mbw == M && nb == N && occ == O && prec == H) {                                               \
     static bool attr_set[64] = {false};                                                             \
     int dev = 0;                                                                                    \
     (void)hipGetDevice(&dev);                                                                       \
@@ -383,7 +459,7 @@ hipError_t launch_conv_ups(const ConvArgs &a_in, int mbw, int planes, int nbp, h
     hipLaunchKernelGGL((conv_ups_kernel<M, N, O, H>), grid, dim3(256), lds, st, a, tb.tH, tb.tM, tb.HV, tb.ntp, HX, HYX, planes, nbp); \
     return hipGetLastError();                                                                       \
   }
-#define CM_UPS_OCCS(M, N) CM_UPS_GO(M, N, 2, false) CM_UPS_GO(M, N, 2, true)
+#define CM_UPS_OCCS(M, N) CM_UPS_GO(M, N, 2, 0) CM_UPS_GO(M, N, 2, 1) CM_UPS_GO(M, N, 2, 2)
   CM_UPS_OCCS(1, 1) CM_UPS_OCCS(2, 1) CM_UPS_OCCS(3, 1) CM_UPS_OCCS(4, 1) CM_UPS_OCCS(5, 1) CM_UPS_OCCS(2, 2)
 #undef CM_UPS_OCCS
 #undef CM_UPS_GO

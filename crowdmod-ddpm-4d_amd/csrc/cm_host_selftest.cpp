@@ -227,6 +227,22 @@ void test_round3_packers() {
           EXPECT(h[o] == f32_to_f16_bits(wi[((size_t)co * Ci + ci) * 27 + t]));
         }
       }
+      // pack_ups_b6: hi + mid + lo reproduces every weight EXACTLY (8 + 8 + 8 mantissa bits), at the documented positions
+      if (Ci % 32 == 0) {
+        std::vector<float> w8((size_t)Co * Ci * 8);
+        for (auto &v : w8) v = U(rng) * (rng() % 7 == 0 ? 1e-6f : 1.f);
+        const std::vector<float> f = pack_ups_b6(w8.data(), Co, Ci);
+        EXPECT(f.size() * 2 == w8.size() * 3);
+        const uint16_t *h = reinterpret_cast<const uint16_t *>(f.data());
+        for (int probe = 0; probe < 200; ++probe) {
+          const int co = (int)(rng() % Co), ci = (int)(rng() % Ci), t = (int)(rng() % 8);
+          const int cbk = co / 32, ch = ci / 32, mg = (ci % 32) / 16, lane = 32 * ((ci % 16) / 8) + co % 32, i = ci % 8;
+          float sum = 0.f;
+          for (int tm = 2; tm >= 0; --tm)
+            sum += bf16_bits_to_f32(h[(((((((size_t)cbk * (Ci / 32) + ch) * 8 + t) * 2 + mg) * 3 + tm) * 64) + lane) * 8 + i]);
+          EXPECT(sum == w8[((size_t)co * Ci + ci) * 8 + t]);
+        }
+      }
       // pack_ups_f16 (one parity class, [Co][Ci][8]): [column block][chunk][tap][16-channel group][lane][8]
       if (Ci % 32 == 0) {
         std::vector<float> w8((size_t)Co * Ci * 8);

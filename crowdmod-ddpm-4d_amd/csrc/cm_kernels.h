@@ -100,6 +100,8 @@ bool conv_ups_pick(int Z, int Y, int X, int *tz, int *ty, int *tx, int *mbw, int
 bool conv_ups_ok(const ConvArgs &a, int mbw, int planes, int nbp);
 int conv_ups_slots(const ConvArgs &a, int mbw);
 hipError_t launch_conv_ups(const ConvArgs &a, int mbw, int planes, int nbp, hipStream_t st);
+// bf16 x 3 split fragments (pack_ups_b6 order) re-derived on the device from the fp32 parity fragments (after an optimizer step)
+hipError_t launch_ups_b6_repack(const float *wfrag, long long wpar_stride, float *w6, long long w6_stride, int Co, int Ci, int NBP, hipStream_t st);
 // 3x3x3 conv with <= 8 output channels on the vector ALUs (cm_conv_small.hip); weights packed as
 // [chunk][tap][ci in chunk][NCO = 4 or 8] (internal tap order), zero beyond Co.
 bool conv_smalln_ok(const ConvArgs &a, int MB);

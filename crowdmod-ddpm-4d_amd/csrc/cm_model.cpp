@@ -115,6 +115,8 @@ struct Op {
   int ups_tz = 0, ups_ty = 0, ups_tx = 0, ups_mbw = 0, ups_planes = 0;
   float *d_wups16 = nullptr;    // its f16 fragments under the reduced-precision plan (pack_ups_f16), floats per parity class
   long long wups16_stride = 0;
+  float *d_wups_b6 = nullptr;   // fp32 plan, inference forward: bf16 x 3 split fragments (pack_ups_b6) for the six-term products
+  long long wups_b6_stride = 0;
   float *d_w16d = nullptr, *d_w16d_skip = nullptr;
   bool qr = false;          // whole-sample kernel of the lowest resolution (cm_conv_qr.hip), inference plan
   float *d_wqr = nullptr, *d_wqr_skip = nullptr;
@@ -439,6 +441,53 @@ std::vector<float> pack_ups_f16(const float *W, int Co, int Ci) {
             for (int i = 0; i < 8; ++i, ++o) {
               const int co = cb * 32 + (lane & 31), ci = ch * 32 + 16 * mg + 8 * (lane >> 5) + i;
               out[o] = f32_to_f16_bits(W[((size_t)co * Ci + ci) * 8 + t]);
+            }
+  std::vector<float> packed(out.size() / 2);
+  std::memcpy(packed.data(), out.data(), out.size() * 2);
+  return packed;
+}
+
+// round-to-nearest-even fp32 -> bf16 (bits)
+static inline uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf16_bits_to_f32(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+// exact three-way bf16 split of an fp32 value: w = hi + mid + lo (each rounded to nearest from the running remainder;
+// 8 + 8 + 8 mantissa bits, the remainders are exact in fp32)
+static inline void bf16_split3(float w, uint16_t out[3]) {
+  float rem = w;
+  for (int t = 0; t < 3; ++t) {
+    out[t] = f32_to_bf16_bits(rem);
+    rem -= bf16_bits_to_f32(out[t]);
+  }
+}
+
+// bf16 x 3 fragments of ONE parity class for the stage-once upsample kernel (cm_conv_ups.hip, PREC = 2): [32-channel column
+// block][32-channel chunk][tap 8][16-channel group m][term hi / mid / lo][lane][8 bf16], lane = 32 hh + (co % 32),
+// ci = chunk * 32 + 16 m + 8 hh + i.  W: [Co][Ci][8] (parity_weights of one class).  Returned as floats holding two bf16 each.
+std::vector<float> pack_ups_b6(const float *W, int Co, int Ci) {
+  const int ncb = Co / 32, nch = Ci / 32;
+  std::vector<uint16_t> out((size_t)ncb * nch * 8 * 2 * 3 * 64 * 8, 0);
+  for (int cb = 0; cb < ncb; ++cb)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int t = 0; t < 8; ++t)
+        for (int mg = 0; mg < 2; ++mg)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int i = 0; i < 8; ++i) {
+              const int co = cb * 32 + (lane & 31), ci = ch * 32 + 16 * mg + 8 * (lane >> 5) + i;
+              uint16_t t3[3];
+              bf16_split3(W[((size_t)co * Ci + ci) * 8 + t], t3);
+              for (int tm = 0; tm < 3; ++tm)
+                out[(((((((size_t)cb * nch + ch) * 8 + t) * 2 + mg) * 3 + tm) * 64) + lane) * 8 + i] = t3[tm];
             }
   std::vector<float> packed(out.size() / 2);
   std::memcpy(packed.data(), out.data(), out.size() * 2);
@@ -812,6 +861,17 @@ int add_conv(cm_model *m, const ConvSpec &s) {
       cm::conv_ups_pick(a.Zs, a.Ys, a.Xs, &op.ups_tz, &op.ups_ty, &op.ups_tx, &op.ups_mbw, &op.ups_planes) &&
       (a.Zs / op.ups_tz) * (a.Ys / op.ups_ty) * (a.Xs / op.ups_tx) * 8 * op.ups_mbw <= MAX_SLOTS)   // (its statistics slots must fit)
     op.ups = true;
+  if (op.ups && m->precision != CM_PRECISION_F16 && Ci_ref == Ci_pad && Ci_ref % 32 == 0 && !cm::diag_env("CM_NO_UPS_B6")) {
+    const std::vector<float> wp = parity_weights(wi, (int)w.shape[0], Ci_ref);
+    const size_t per = (size_t)w.shape[0] * Ci_ref * 8;
+    std::vector<float> wb6;
+    for (int p8 = 0; p8 < 8; ++p8) {
+      const std::vector<float> one = pack_ups_b6(wp.data() + p8 * per, (int)w.shape[0], Ci_ref);
+      op.wups_b6_stride = (long long)one.size();
+      wb6.insert(wb6.end(), one.begin(), one.end());
+    }
+    if (upload(m, wb6, &op.d_wups_b6)) return 1;
+  }
   if (op.ups && m->precision == CM_PRECISION_F16 && Ci_ref == Ci_pad && Ci_ref % 32 == 0 && !cm::diag_env("CM_NO_UPS_F16")) {
     const std::vector<float> wp = parity_weights(wi, (int)w.shape[0], Ci_ref);
     const size_t per = (size_t)w.shape[0] * Ci_ref * 8;
@@ -1335,6 +1395,7 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     // upsample conv: stage-once parity kernel with its own source tile / statistics slots (f16 operands under the
     // reduced-precision plan's inference forward)
     if (op.d_wups16 && !m->train_fwd) { ca.wfrag = op.d_wups16; ca.wpar_stride = op.wups16_stride; ca.f16 = 1; }
+    else if (op.d_wups_b6 && !m->train_fwd) { ca.wfrag = op.d_wups_b6; ca.wpar_stride = op.wups_b6_stride; ca.f16 = 2; }   // six-term bf16 products
     ca.bz = op.ups_tz; ca.by = op.ups_ty; ca.bx = op.ups_tx;
     ca.ntz = ca.Zs / ca.bz; ca.nty = ca.Ys / ca.by; ca.ntx = ca.Xs / ca.bx;
     if (op.stat_act) {
