@@ -35,6 +35,8 @@ namespace cm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -533,15 +535,19 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
 // Same arithmetic in the same order as conv_wino_kernel<..., TWO = true>: results are bit-identical to it.
 // SKIP: the block's 1x1x1 skip convolution is contracted onto the finished sub-block (its own instantiation, so that the
 // plain layers do not carry its registers: with it in one body the kernel spilled ~100 registers).
-template <int BZ, int PY, int PX, bool F16, int NBW, bool SKIP>
+// B6: fp32 products from exact three-way bf16 splits (cm_conv_ups.hip explains the arithmetic): the transformed input is split
+// into hi / mid / lo planes at the U write, the transformed weights arrive pre-split (pack_wino_b6), and 16 channels of a
+// (z tap, component) are six v_mfma_f32_32x32x16_bf16 (192 cycles) instead of eight fp32 instructions (512 cycles).
+template <int BZ, int PY, int PX, bool F16, int NBW, bool SKIP, bool B6 = false>
 __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArgs a, const int *__restrict__ tabA,
                                                                   const int *__restrict__ tabO, int G) {
   constexpr int NT = 256 * NBW;
   constexpr int NP = PY * PX, ROWS = BZ * NP;
   static_assert(ROWS <= 32 && ROWS > 16, "one (partly filled) 32-row accumulator block per frequency component");
   constexpr int HZ = BZ + 2, UR = HZ * NP;
-  constexpr bool SWZ = !F16 && PY * PX == 4;
-  constexpr int CS = 16, S = F16 ? 12 : (SWZ ? CS : CS + 4);
+  static_assert(!(F16 && B6), "one operand format");
+  constexpr bool SWZ = !F16 && !B6 && PY * PX == 4;
+  constexpr int CS = 16, S = B6 ? 28 : (F16 ? 12 : (SWZ ? CS : CS + 4));   // B6: three bf16 planes of 8 dwords + 4 pad
   constexpr int RYH = 2 * PY + 2, RXH = 2 * PX + 2, RV = HZ * RYH * RXH, RS_ = BZ == 8 ? 24 : 20;
   constexpr int RK = (RV * 4 + NT - 1) / NT;
   constexpr int NITEMS = HZ * NP * (CS / 4);
@@ -579,19 +585,30 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
   const int it = stager ? tid : 0;
   const int quad = it & 3, patch = (it >> 2) % NP, zi = it / (4 * NP);
   const int urow = zi * NP + patch;
-  float *const uw = U + (size_t)urow * S + (F16 ? 2 : 4) * (SWZ ? (quad ^ ((urow >> 2) & 3)) : quad);
+  float *const uw = U + (size_t)urow * S + ((F16 || B6) ? 2 : 4) * (SWZ ? (quad ^ ((urow >> 2) & 3)) : quad);
   const int rbase = ((zi * RYH + 2 * (patch / PX)) * RXH + 2 * (patch % PX)) * RS_ + 4 * quad;
 
   const int n0 = a.C0 >> 4, nchunks = n0 + (a.C1 >> 4);
   const int Ctot = a.C0 + a.C1;
   const unsigned Vs = (unsigned)(a.Zs * a.Ys * a.Xs), Vo = (unsigned)(a.Zo * a.Yo * a.Xo);
-  constexpr int NG = F16 ? 3 : 6;
-  const f32x4 *wbase = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * nchunks * (4 * NG * 4 * 64) + wave * (NG * 4 * 64) + lane;
+  constexpr int NG = (F16 || B6) ? 3 : 6;
+  constexpr int NTM = B6 ? 3 : 1;                   // operand terms per fragment
+  const f32x4 *wbase = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * nchunks * (4 * NG * 4 * NTM * 64) + wave * (NG * 4 * NTM * 64) + lane;
   constexpr int RS = F16 ? 3 : 2;
-  static_assert(NG % RS == 0, "ring slots must line up at chunk boundaries");
-  f32x4 bq[RS][4];
+  static_assert(B6 || NG % RS == 0, "ring slots must line up at chunk boundaries");
+  f32x4 bq[B6 ? 1 : RS][4];
+  // B6: ring over the 12 (z tap, component) steps of a chunk, three term fragments per step, RD6 steps ahead
+  constexpr int RD6 = 4;
+  f32x4 b6[B6 ? RD6 : 1][3];
+  if constexpr (B6) {
 #pragma unroll
-  for (int x = 0; x < 4; ++x) bq[0][x] = wbase[x * 64];
+    for (int sx = 0; sx < RD6; ++sx)
+#pragma unroll
+      for (int tm = 0; tm < 3; ++tm) b6[sx][tm] = wbase[(sx * 3 + tm) * 64];
+  } else {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) bq[0][x] = wbase[x * 64];
+  }
 
   const int ar = min(r, ROWS - 1);
   const float *arow = U + (size_t)(wave * 4) * UR * S + (size_t)ar * S + (SWZ ? 0 : 4 * hh);
@@ -692,7 +709,15 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-          if constexpr (F16) {
+          if constexpr (B6) {
+            f32x4 rem = d[k];
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) {
+              const bf16x4 hb = {(__bf16)rem[0], (__bf16)rem[1], (__bf16)rem[2], (__bf16)rem[3]};
+              *reinterpret_cast<bf16x4 *>(uw + (size_t)k * UR * S + 8 * tm) = hb;
+              if (tm < 2) rem = rem - f32x4{(float)hb[0], (float)hb[1], (float)hb[2], (float)hb[3]};   // exact remainder
+            }
+          } else if constexpr (F16) {
             const f16x4 hv = {(_Float16)d[k][0], (_Float16)d[k][1], (_Float16)d[k][2], (_Float16)d[k][3]};
             *reinterpret_cast<f16x4 *>(uw + (size_t)k * UR * S) = hv;
           } else {
@@ -711,6 +736,43 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
 #pragma unroll
         for (int x = 0; x < 4; ++x) af[x] = *reinterpret_cast<const f32x4 *>(arow + (size_t)x * UR * S + (size_t)dz * NP * S + acol);
       };
+      if constexpr (B6) {
+        const float *ab = arow;                    // (F16-style fragment: 8 halves per lane at 4 hh dwords, planes 8 dwords apart)
+        f32x4 af6[2][3];
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) af6[0][tm] = *reinterpret_cast<const f32x4 *>(ab + 8 * tm);
+#pragma unroll
+        for (int sx = 0; sx < 12; ++sx) {          // step = (z tap g, component x)
+          const int g = sx >> 2, x = sx & 3;
+          (void)g; (void)x;
+          if (sx + 1 < 12) {
+            const int g1 = (sx + 1) >> 2, x1 = (sx + 1) & 3;
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm)
+              af6[(sx + 1) & 1][tm] = *reinterpret_cast<const f32x4 *>(ab + (size_t)x1 * UR * S + (size_t)g1 * NP * S + 8 * tm);
+          }
+          // (A term, B term), small products first: hi = 0, mid = 1, lo = 2
+          constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+          for (int u = 0; u < 6; ++u)
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af6[sx & 1][TA[u]]),
+                                                             __builtin_bit_cast(bf16x8, b6[sx % RD6][TB[u]]), acc[x], 0, 0, 0);
+          // refill the slot just read with step sx + RD6 (of this chunk, the next one, or the next sample's first)
+          {
+            constexpr int CHS = 4 * NG * 4 * 3 * 64;
+            const int sn = sx + RD6;
+            const bool wraps = sn >= 12;
+            const bool more = !wraps || ch + 1 < nchunks || more_b;
+            const int cn = !wraps ? ch : (ch + 1 < nchunks ? ch + 1 : 0);
+            const f32x4 *wn = wbase + (size_t)cn * CHS + (size_t)((wraps ? sn - 12 : sn) * 3) * 64;
+            if (more) {
+#pragma unroll
+              for (int tm = 0; tm < 3; ++tm) b6[sx % RD6][tm] = wn[tm * 64];
+            }
+          }
+          asm volatile("" ::: "memory");
+        }
+      } else {
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         {
@@ -735,6 +797,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
             for (int x = 0; x < 4; ++x)
               acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x][jj], bq[g % RS][x][jj], acc[x], 0, 0, 0);
         }
+      }
       }
     }
 
@@ -923,9 +986,9 @@ bool conv_wino_ok(const ConvArgs &a) {
          a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo && conv_wino_lds(a.bz, a.by, a.bx, false, conv_wino_nbw(a.bz, a.Co)) <= (conv_wino_nbw(a.bz, a.Co) == 2 ? 160 : 80) * 1024;
 }
 
-size_t conv_wino_p_lds(int bz, int by, int bx, bool f16, int nbw) {
+size_t conv_wino_p_lds(int bz, int by, int bx, bool f16, int nbw, bool b6) {
   const size_t ur = (size_t)(bz + 2) * (by / 2) * (bx / 2);
-  const size_t u = 16 * ur * (f16 ? 12 : (by * bx == 16 ? 16 : 20));
+  const size_t u = 16 * ur * (b6 ? 28 : (f16 ? 12 : (by * bx == 16 ? 16 : 20)));
   const size_t x = (size_t)nbw * 4 * 2 * 16 * 64;
   const size_t rimg = (size_t)(bz + 2) * (by + 2) * (bx + 2) * (bz == 8 ? 24 : 20);
   return (128 + std::max(u, x) + rimg) * sizeof(float);       // R behind max(U, exchange): see conv_wino_p_kernel
@@ -969,11 +1032,52 @@ static int wino_cu_count() {
   return c;
 }
 
+// Split fragments of the six-term form, re-derived on the device from the fp32 Winograd fragments (pack_wino order
+// [n tile][chunk][xi_y][step = (dz * 2 + k8) * 4 + xi_x][lane][4], ci = chunk * 16 + 8 k8 + 4 hh + jj) into pack_wino_b6 order
+// [n tile][chunk][xi_y][dz][xi_x][term][lane][8 bf16], ci = chunk * 16 + 8 hh + j.  One thread per transformed weight.
+__global__ __launch_bounds__(256) void wino_b6_repack_kernel(const float *__restrict__ wf, unsigned short *__restrict__ w6, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  // i enumerates the SOURCE order: (((((nt * nch + chunk) * 4 + xy) * 24 + step) * 64) + lane) * 4 + jj
+  const int jj = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  long long q = i >> 8;
+  const int step = (int)(q % 24); q /= 24;
+  const int xy = (int)(q & 3);
+  const long long tc = q >> 2;                       // nt * nch + chunk
+  const int xx = step & 3, k8 = (step >> 2) & 1, dz = step >> 3;
+  const int r = lane & 31, hs = lane >> 5;
+  const int cl = 8 * k8 + 4 * hs + jj;               // channel within the 16-channel chunk
+  const int hd = cl >> 3, j = cl & 7;
+  unsigned short *dst = w6 + ((((((size_t)tc * 4 + xy) * 3 + dz) * 4 + xx) * 3) * 64 + 32 * hd + r) * 8 + j;
+  float rem = wf[i];
+#pragma unroll
+  for (int tm = 0; tm < 3; ++tm) {
+    const __bf16 hb = (__bf16)rem;
+    dst[(size_t)tm * 64 * 8] = __builtin_bit_cast(unsigned short, hb);
+    rem -= (float)hb;
+  }
+}
+
+hipError_t launch_wino_b6_repack(const float *wwino, float *w6, long long n_floats, hipStream_t st) {
+  if (n_floats <= 0 || n_floats % (4 * 24 * 64 * 4)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(wino_b6_repack_kernel, dim3((unsigned)((n_floats + 255) / 256)), dim3(256), 0, st, wwino,
+                     reinterpret_cast<unsigned short *>(w6), n_floats);
+  return hipGetLastError();
+}
+
+// can this layer run the six-term bf16 form (wfrag = pack_wino_b6 fragments, a.f16 = 2)?  Two-tile table-driven kernel only.
+bool conv_wino_b6_ok(int bz, int by, int bx, int Co) {
+  return bz != 8 && conv_wino_tile_ok(bz, by, bx) && conv_wino_nbw(bz, Co) == 2 && conv_wino_p_lds(bz, by, bx, false, 2, true) <= 160 * 1024 &&
+         !cm::diag_env("CM_NO_WINO_P");
+}
+
 hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
   ConvArgs a = a_in;
   a.dbg = conv_dbg_flags();
   if (!conv_wino_ok(a)) return hipErrorInvalidValue;
   const int nbw = conv_wino_nbw(a.bz, a.Co);
+  const bool b6 = a.f16 == 2;
+  if (b6 && (f16 || !conv_wino_b6_ok(a.bz, a.by, a.bx, a.Co))) return hipErrorInvalidValue;
   static const bool no_p = cm::diag_env("CM_NO_WINO_P") != nullptr;
 #define CM_WINO_ATTR(KERNEL)                                                                        \
     static bool attr_set[64] = {false};                                                             \
@@ -992,7 +1096,7 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
   // sample lanes balance worse (85 vs 79 us).  CM_WINO_P=1 under CM_DIAG forces it everywhere for A/B runs.
   static const bool all_p = cm::diag_env("CM_WINO_P") != nullptr;
   if (conv_wino_two_step(a.bz, a.by, a.bx, f16, nbw) && !no_p && (nbw == 2 || all_p)) {
-    const size_t ldsp = conv_wino_p_lds(a.bz, a.by, a.bx, f16, nbw);
+    const size_t ldsp = conv_wino_p_lds(a.bz, a.by, a.bx, f16, nbw, b6);
     const int ntp = a.ntz * a.nty * a.ntx, nz = (a.Co + 31) / 32 / nbw;
     const int per_cu = (nbw == 1 && 2 * ldsp <= 160 * 1024) ? 2 : 1;
     const int slots = wino_cu_count() * per_cu;
@@ -1013,9 +1117,15 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
     if (a.s2w) CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, F, NB, true>), THREADS)                \
     CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, F, NB, false>), THREADS)                          \
   }
+#define CM_WINO_PGO6(Z, PY_, PX_, THREADS)                                                          \
+  {                                                                                                 \
+    if (a.s2w) CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, 2, true, true>), THREADS)       \
+    CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, 2, false, true>), THREADS)                 \
+  }
 #define X(z, py, px)                                                                                \
     if (a.bz == z && a.by == 2 * py && a.bx == 2 * px && ldsp <= 160 * 1024) {                      \
       if constexpr (z != 8) {                                                                       \
+        if (nbw == 2 && b6) CM_WINO_PGO6(z, py, px, 512)                                            \
         if (nbw == 2 && f16) CM_WINO_PGO(z, py, px, true, 2, 512)                                   \
         if (nbw == 2) CM_WINO_PGO(z, py, px, false, 2, 512)                                         \
       }                                                                                             \
@@ -1025,6 +1135,7 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
     CM_WINO_TILES(X)
 #undef X
   }
+  if (b6) return hipErrorInvalidValue;            // (only the table-driven kernel has the six-term form)
   const dim3 grid((unsigned)(a.B * a.ntz * a.nty * a.ntx), (unsigned)((a.Co + 31) / 32 / nbw));
   const size_t lds = conv_wino_lds(a.bz, a.by, a.bx, f16, nbw);
 #define CM_WINO_GO(KERNEL, THREADS)                                                                 \

@@ -126,6 +126,10 @@ size_t conv_wino_lds(int bz, int by, int bx, bool f16, int nbw);
 int conv_wino_nbw(int bz, int Co);
 // f16: a.wfrag holds the f16 packing (3 groups per chunk and wave, 8 halves per lane): fp32 accumulate, f16 operands
 hipError_t launch_conv_wino(const ConvArgs &a, bool f16, hipStream_t st);
+// six-term bf16 form (a.f16 = 2, wfrag = pack_wino_b6 fragments): two-tile table-driven kernel only
+bool conv_wino_b6_ok(int bz, int by, int bx, int Co);
+// its split fragments from the fp32 Winograd fragments (n_floats of them), e.g. after an optimizer step
+hipError_t launch_wino_b6_repack(const float *wwino, float *w6, long long n_floats, hipStream_t st);
 // Weight gradient in the Winograd domain (same tiles): partials part[G][ncb][nkb][3][16][32 ci][32 co], then G^T dU G
 hipError_t launch_wgrad_wino(const ConvArgs &a, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb, hipStream_t st);
 hipError_t launch_wgrad_wino_reduce(const float *part, int G, int ncb, int nkb, int Co, int Ci, float *dW, hipStream_t st);

@@ -107,6 +107,8 @@ struct Op {
   bool wino = false;        // Winograd F(2x2,3x3) kernel (cm_conv_wino.hip): full-resolution stride-1 3x3x3 layers
   float *d_wwino = nullptr;
   float *d_wwino16 = nullptr;   // the same weights as f16 operands (reduced-precision plan, cm_model_set_precision)
+  float *d_wwino_b6 = nullptr;  // fp32 plan, inference forward, two-tile layers: exact bf16 x 3 split of d_wwino (pack_wino_b6)
+  long long wwino_floats = 0;   // element count of d_wwino
   float *d_wfrag16 = nullptr;   // f16 fragments of a parity-form upsample conv (reduced-precision plan)
   long long wpar_stride16 = 0;
   bool f16d = false;        // reduced-precision plan: direct f16-operand kernel (cm_conv_f16.hip) instead of the Winograd one
@@ -592,6 +594,31 @@ std::vector<float> pack_wino_f16(const std::vector<float> &wi, int Co, int Ci, i
   return packed;
 }
 
+// Six-term bf16 form of the Winograd layers (conv_wino_p_kernel<..., B6>): the fp32 fragments of pack_wino
+// ([n tile][chunk][xi_y][step = (dz * 2 + k8) * 4 + xi_x][lane][4], ci = chunk * 16 + 8 k8 + 4 hh + jj) split exactly into three
+// bf16 terms and regrouped as [n tile][chunk][xi_y][dz][xi_x][term][lane][8 bf16], ci = chunk * 16 + 8 hh + j.  The device
+// re-derives the same thing after an optimizer step (wino_b6_repack_kernel): one definition, two places -- the self-test
+// compares them element by element.
+std::vector<float> pack_wino_b6(const std::vector<float> &ww) {
+  std::vector<uint16_t> out(ww.size() * 3, 0);
+  for (size_t i = 0; i < ww.size(); ++i) {
+    const int jj = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    size_t q = i >> 8;
+    const int step = (int)(q % 24); q /= 24;
+    const int xy = (int)(q & 3);
+    const size_t tc = q >> 2;
+    const int xx = step & 3, k8 = (step >> 2) & 1, dz = step >> 3;
+    const int r = lane & 31, hs = lane >> 5, cl = 8 * k8 + 4 * hs + jj, hd = cl >> 3, j = cl & 7;
+    uint16_t t3[3];
+    bf16_split3(ww[i], t3);
+    for (int tm = 0; tm < 3; ++tm)
+      out[(((((((tc * 4 + xy) * 3 + dz) * 4 + xx) * 3 + tm) * 64) + 32 * hd + r) * 8) + j] = t3[tm];
+  }
+  std::vector<float> packed(out.size() / 2);
+  std::memcpy(packed.data(), out.data(), out.size() * 2);
+  return packed;
+}
+
 int pick_ck(int C0, int C1) {
   for (int ck : {32, 16, 8})
     if (C0 % ck == 0 && C1 % ck == 0) return ck;
@@ -904,6 +931,13 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     pack_wino(&wi, nullptr, s.Co, Ci_ref, Ci_pad, &ww, nullptr, nullptr);
     if (upload(m, ww, &op.d_wwino)) return 1;
     if (m->precision == CM_PRECISION_F16 && upload(m, pack_wino_f16(wi, s.Co, Ci_ref, Ci_pad), &op.d_wwino16)) return 1;
+    op.wwino_floats = (long long)ww.size();
+    {
+      int wz = 0, wy = 0, wx = 0;
+      if (m->precision != CM_PRECISION_F16 && !cm::diag_env("CM_NO_WINO_B6") && cm::conv_wino_pick(s.out->Z, s.out->Y, s.out->X, &wz, &wy, &wx) &&
+          cm::conv_wino_b6_ok(wz, wy, wx, s.Co) && upload(m, pack_wino_b6(ww), &op.d_wwino_b6))
+        return 1;
+    }
     // reduced-precision plan: the direct f16 kernel replaces the Winograd one where its tiles fit (no transforms to pay for
     // when the matrix instruction is 16x faster)
     // (measured on the 24x72 grid, B = 32: 61 vs 70 us on the 32 -> 32 full-resolution layer, 136 vs 154 us on 96 -> 32, 72 vs 76 us
@@ -1425,6 +1459,8 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     // reduced-precision plan: f16 operands in the inference forward; the training forward stays fp32
     const bool f16 = op.d_wwino16 && !m->train_fwd;
     ca.wfrag = f16 ? op.d_wwino16 : op.d_wwino;
+    // two-tile layers, fp32 plan, inference forward: six-term bf16 products (same tile geometry as the plan picked)
+    if (!f16 && op.d_wwino_b6 && !m->train_fwd && cm::conv_wino_b6_ok(ca.bz, ca.by, ca.bx, ca.Co)) { ca.wfrag = op.d_wwino_b6; ca.f16 = 2; }
     CM_HIP(cm::launch_conv_wino(ca, f16, st));
   } else if (op.first_k) {
     CM_HIP(cm::launch_conv_first(ca, op.first_cin, op.d_wfirst, st));
