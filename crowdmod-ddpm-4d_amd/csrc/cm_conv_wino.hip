@@ -581,8 +581,14 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
     asoff[k] = asoff[k] >= 0 ? asoff[k] : 0;
   }
   const int aq = tid & 3;
-  const bool stager = tid < NITEMS;
-  const int it = stager ? tid : 0;
+  // transform items (plane, patch, channel quad).  When the workgroup has twice as many threads as items (two-tile form),
+  // both halves of the workgroup take every item: waves 0-3 compute the frequency columns xi_x in {0, 1}, waves 4-7 {2, 3}
+  // (eight of the sixteen components each; the half is wave-uniform, so nothing is computed twice) -- the transform runs on
+  // all eight waves instead of four, with half the arithmetic per thread
+  constexpr bool HX2 = NT == 512 && NITEMS <= 256;
+  const int itid = HX2 ? (tid & 255) : tid, hf = HX2 ? wv8 >> 2 : 0;
+  const bool stager = itid < NITEMS;
+  const int it = stager ? itid : 0;
   const int quad = it & 3, patch = (it >> 2) % NP, zi = it / (4 * NP);
   const int urow = zi * NP + patch;
   float *const uw = U + (size_t)urow * S + ((F16 || B6) ? 2 : 4) * (SWZ ? (quad ^ ((urow >> 2) & 3)) : quad);
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
   static_assert(B6 || NG % RS == 0, "ring slots must line up at chunk boundaries");
   f32x4 bq[B6 ? 1 : RS][4];
   // B6: ring over the 12 (z tap, component) steps of a chunk, three term fragments per step, RD6 steps ahead
-  constexpr int RD6 = 4;
+  constexpr int RD6 = 3;
   f32x4 b6[B6 ? RD6 : 1][3];
   if constexpr (B6) {
 #pragma unroll
@@ -697,20 +703,9 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) d[i * 4 + j] = *reinterpret_cast<const f32x4 *>(R + rbase + (i * RXH + j) * RS_);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f32x4 e0 = d[i * 4 + 0], e1 = d[i * 4 + 1], e2 = d[i * 4 + 2], e3 = d[i * 4 + 3];
-          d[i * 4 + 0] = pk_sub(e0, e2); d[i * 4 + 1] = e1 + e2; d[i * 4 + 2] = pk_sub(e2, e1); d[i * 4 + 3] = pk_sub(e1, e3);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j], e3 = d[3 * 4 + j];
-          d[0 * 4 + j] = pk_sub(e0, e2); d[1 * 4 + j] = e1 + e2; d[2 * 4 + j] = pk_sub(e2, e1); d[3 * 4 + j] = pk_sub(e1, e3);
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        auto put = [&](int k, const f32x4 v) {     // component k = xi_y * 4 + xi_x of this item
           if constexpr (B6) {
-            f32x4 rem = d[k];
+            f32x4 rem = v;
 #pragma unroll
             for (int tm = 0; tm < 3; ++tm) {
               const bf16x4 hb = {(__bf16)rem[0], (__bf16)rem[1], (__bf16)rem[2], (__bf16)rem[3]};
@@ -718,11 +713,41 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
               if (tm < 2) rem = rem - f32x4{(float)hb[0], (float)hb[1], (float)hb[2], (float)hb[3]};   // exact remainder
             }
           } else if constexpr (F16) {
-            const f16x4 hv = {(_Float16)d[k][0], (_Float16)d[k][1], (_Float16)d[k][2], (_Float16)d[k][3]};
+            const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             *reinterpret_cast<f16x4 *>(uw + (size_t)k * UR * S) = hv;
           } else {
-            *reinterpret_cast<f32x4 *>(uw + (size_t)k * UR * S) = d[k];
+            *reinterpret_cast<f32x4 *>(uw + (size_t)k * UR * S) = v;
           }
+        };
+        if constexpr (HX2) {
+          // x pass: only this lane's two frequency columns; y pass on them; same operations per component as the full form
+          f32x4 c[4][2];
+          if (hf == 0) {                           // (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { c[i][0] = pk_sub(d[i * 4 + 0], d[i * 4 + 2]); c[i][1] = d[i * 4 + 1] + d[i * 4 + 2]; }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { c[i][0] = pk_sub(d[i * 4 + 2], d[i * 4 + 1]); c[i][1] = pk_sub(d[i * 4 + 1], d[i * 4 + 3]); }
+          }
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const f32x4 e0 = c[0][jj], e1 = c[1][jj], e2 = c[2][jj], e3 = c[3][jj];
+            const int j = 2 * hf + jj;
+            put(0 * 4 + j, pk_sub(e0, e2)); put(1 * 4 + j, e1 + e2); put(2 * 4 + j, pk_sub(e2, e1)); put(3 * 4 + j, pk_sub(e1, e3));
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x4 e0 = d[i * 4 + 0], e1 = d[i * 4 + 1], e2 = d[i * 4 + 2], e3 = d[i * 4 + 3];
+            d[i * 4 + 0] = pk_sub(e0, e2); d[i * 4 + 1] = e1 + e2; d[i * 4 + 2] = pk_sub(e2, e1); d[i * 4 + 3] = pk_sub(e1, e3);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j], e3 = d[3 * 4 + j];
+            d[0 * 4 + j] = pk_sub(e0, e2); d[1 * 4 + j] = e1 + e2; d[2 * 4 + j] = pk_sub(e2, e1); d[3 * 4 + j] = pk_sub(e1, e3);
+          }
+#pragma unroll
+          for (int k = 0; k < 16; ++k) put(k, d[k]);
         }
       }
       __syncthreads();
