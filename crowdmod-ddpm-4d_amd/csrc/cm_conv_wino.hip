@@ -547,12 +547,18 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
   constexpr int HZ = BZ + 2, UR = HZ * NP;
   static_assert(!(F16 && B6), "one operand format");
   constexpr bool SWZ = !F16 && !B6 && PY * PX == 4;
-  constexpr int CS = 16, S = B6 ? 28 : (F16 ? 12 : (SWZ ? CS : CS + 4));   // B6: three bf16 planes of 8 dwords + 4 pad
-  constexpr int RYH = 2 * PY + 2, RXH = 2 * PX + 2, RV = HZ * RYH * RXH, RS_ = BZ == 8 ? 24 : 20;
+  // CMP (B6 on the full-resolution tile, BZ = Zs = 8): the two zero-padding planes of the halo get NO rows -- U keeps one zero
+  // block (rows [0, NP): it is halo plane 0, and halo plane 9 reads it too), R keeps the eight real planes only, rows are
+  // unpadded -- so that the three bf16 planes of U (55 KB) and R (23 KB) still fit two workgroups per CU
+  constexpr bool CMP = B6 && BZ == 8;
+  constexpr int URC = CMP ? (HZ - 1) * NP : UR;          // U rows per component
+  constexpr int CS = 16, S = CMP ? 24 : (B6 ? 28 : (F16 ? 12 : (SWZ ? CS : CS + 4)));   // B6: three bf16 planes of 8 dwords (+ 4 pad)
+  constexpr int RYH = 2 * PY + 2, RXH = 2 * PX + 2, RV = HZ * RYH * RXH, RS_ = CMP ? 20 : (BZ == 8 ? 24 : 20);
+  constexpr int PLV = RYH * RXH, RVC = CMP ? BZ * PLV : RV, RV0 = CMP ? PLV : 0;   // R voxels kept, first kept halo voxel
   constexpr int RK = (RV * 4 + NT - 1) / NT;
   constexpr int NITEMS = HZ * NP * (CS / 4);
   static_assert(NITEMS <= 256, "one staging item per thread");
-  constexpr int USZ = 16 * UR * S, XSZ = NBW * 4 * 2 * 16 * 64;
+  constexpr int USZ = 16 * URC * S, XSZ = NBW * 4 * 2 * 16 * 64;
   constexpr int UX = USZ > XSZ ? USZ : XSZ;          // U, later the exchange buffer: R must NOT overlap it (next tile's step A)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int *outoff = reinterpret_cast<int *>(lds);       // [4 sub-blocks (a, b)][32 rows] in-sample output voxel index or -1
@@ -587,12 +593,12 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
   // all eight waves instead of four, with half the arithmetic per thread
   constexpr bool HX2 = NT == 512 && NITEMS <= 256;
   const int itid = HX2 ? (tid & 255) : tid, hf = HX2 ? wv8 >> 2 : 0;
-  const bool stager = itid < NITEMS;
-  const int it = stager ? itid : 0;
+  const int it = itid < NITEMS ? itid : 0;
   const int quad = it & 3, patch = (it >> 2) % NP, zi = it / (4 * NP);
+  const bool stager = itid < NITEMS && !(CMP && (zi == 0 || zi == HZ - 1));   // CMP: padding planes are never transformed
   const int urow = zi * NP + patch;
   float *const uw = U + (size_t)urow * S + ((F16 || B6) ? 2 : 4) * (SWZ ? (quad ^ ((urow >> 2) & 3)) : quad);
-  const int rbase = ((zi * RYH + 2 * (patch / PX)) * RXH + 2 * (patch % PX)) * RS_ + 4 * quad;
+  const int rbase = (((zi - (CMP ? 1 : 0)) * RYH + 2 * (patch / PX)) * RXH + 2 * (patch % PX)) * RS_ + 4 * quad;
 
   const int n0 = a.C0 >> 4, nchunks = n0 + (a.C1 >> 4);
   const int Ctot = a.C0 + a.C1;
@@ -617,7 +623,12 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
   }
 
   const int ar = min(r, ROWS - 1);
-  const float *arow = U + (size_t)(wave * 4) * UR * S + (size_t)ar * S + (SWZ ? 0 : 4 * hh);
+  const float *arow = U + (size_t)(wave * 4) * URC * S + (size_t)ar * S + (SWZ ? 0 : 4 * hh);
+  // CMP: row block of halo plane z + dz; plane HZ - 1 (top padding) is the zero block 0
+  int rowoff[3] = {0, NP * S, 2 * NP * S};
+  if constexpr (CMP) {
+    if (ar / NP == BZ - 1) rowoff[2] = -(ar / NP) * NP * S;   // z = 7, dz = 2: block 0 instead of block 9
+  }
   // this lane's output rows of the epilogue: reg -> row (reg & 3) + 8 (reg >> 2) + 4 hh of sub-block `wave`
   // (read once per workgroup after the table has landed, below)
 
@@ -679,7 +690,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
           f32x4 w = ald[k] * sc1 + sh1;
           w[0] = silu_w(w[0]); w[1] = silu_w(w[1]); w[2] = silu_w(w[2]); w[3] = silu_w(w[3]);
           if (!((aok >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (v < RV) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = w;
+          if (v >= RV0 && v < RV0 + RVC) *reinterpret_cast<f32x4 *>(R + (v - RV0) * RS_ + 4 * aq) = w;
         }
       } else {
 #pragma unroll
@@ -692,10 +703,17 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
           }
           if (a.pm) w = w * pm1;
           if (!((aok >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (v < RV) *reinterpret_cast<f32x4 *>(R + v * RS_ + 4 * aq) = w;
+          if (v >= RV0 && v < RV0 + RVC) *reinterpret_cast<f32x4 *>(R + (v - RV0) * RS_ + 4 * aq) = w;
         }
       }
       __syncthreads();                          // R complete; every wave is past the previous matrix phase / exchange reads
+      if constexpr (CMP) {
+        if (ch == 0)                              // the zero block (the previous tile's exchange overwrote it)
+          for (int i = tid; i < 16 * NP * (S / 4); i += NT) {
+            const int xi = i / (NP * (S / 4)), rem = i - xi * (NP * (S / 4));
+            *reinterpret_cast<f32x4 *>(U + (size_t)xi * URC * S + 4 * rem) = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
       // ---- step B: B^T d B of the item's 4x4 patch out of R ------------------------------------------------
       if (stager) {
         f32x4 d[16];
@@ -709,14 +727,14 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
 #pragma unroll
             for (int tm = 0; tm < 3; ++tm) {
               const bf16x4 hb = {(__bf16)rem[0], (__bf16)rem[1], (__bf16)rem[2], (__bf16)rem[3]};
-              *reinterpret_cast<bf16x4 *>(uw + (size_t)k * UR * S + 8 * tm) = hb;
+              *reinterpret_cast<bf16x4 *>(uw + (size_t)k * URC * S + 8 * tm) = hb;
               if (tm < 2) rem = rem - f32x4{(float)hb[0], (float)hb[1], (float)hb[2], (float)hb[3]};   // exact remainder
             }
           } else if constexpr (F16) {
             const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-            *reinterpret_cast<f16x4 *>(uw + (size_t)k * UR * S) = hv;
+            *reinterpret_cast<f16x4 *>(uw + (size_t)k * URC * S) = hv;
           } else {
-            *reinterpret_cast<f32x4 *>(uw + (size_t)k * UR * S) = v;
+            *reinterpret_cast<f32x4 *>(uw + (size_t)k * URC * S) = v;
           }
         };
         if constexpr (HX2) {
@@ -759,13 +777,13 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
         const int dz = F16 ? g : g >> 1, k8 = F16 ? 0 : g & 1;
         const int acol = SWZ ? 4 * ((2 * k8 + hh) ^ (((ar >> 2) + dz) & 3)) : 8 * k8;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) af[x] = *reinterpret_cast<const f32x4 *>(arow + (size_t)x * UR * S + (size_t)dz * NP * S + acol);
+        for (int x = 0; x < 4; ++x) af[x] = *reinterpret_cast<const f32x4 *>(arow + (size_t)x * URC * S + (size_t)dz * NP * S + acol);
       };
       if constexpr (B6) {
         const float *ab = arow;                    // (F16-style fragment: 8 halves per lane at 4 hh dwords, planes 8 dwords apart)
         f32x4 af6[2][3];
 #pragma unroll
-        for (int tm = 0; tm < 3; ++tm) af6[0][tm] = *reinterpret_cast<const f32x4 *>(ab + 8 * tm);
+        for (int tm = 0; tm < 3; ++tm) af6[0][tm] = *reinterpret_cast<const f32x4 *>(ab + rowoff[0] + 8 * tm);
 #pragma unroll
         for (int sx = 0; sx < 12; ++sx) {          // step = (z tap g, component x)
           const int g = sx >> 2, x = sx & 3;
@@ -774,7 +792,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
             const int g1 = (sx + 1) >> 2, x1 = (sx + 1) & 3;
 #pragma unroll
             for (int tm = 0; tm < 3; ++tm)
-              af6[(sx + 1) & 1][tm] = *reinterpret_cast<const f32x4 *>(ab + (size_t)x1 * UR * S + (size_t)g1 * NP * S + 8 * tm);
+              af6[(sx + 1) & 1][tm] = *reinterpret_cast<const f32x4 *>(ab + (size_t)x1 * URC * S + rowoff[g1] + 8 * tm);
           }
           // (A term, B term), small products first: hi = 0, mid = 1, lo = 2
           constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
@@ -1012,10 +1030,11 @@ bool conv_wino_ok(const ConvArgs &a) {
 }
 
 size_t conv_wino_p_lds(int bz, int by, int bx, bool f16, int nbw, bool b6) {
-  const size_t ur = (size_t)(bz + 2) * (by / 2) * (bx / 2);
-  const size_t u = 16 * ur * (b6 ? 28 : (f16 ? 12 : (by * bx == 16 ? 16 : 20)));
+  const bool cmp = b6 && bz == 8;                   // compact form: no rows for the two padding planes (conv_wino_p_kernel)
+  const size_t ur = (size_t)(bz + (cmp ? 1 : 2)) * (by / 2) * (bx / 2);
+  const size_t u = 16 * ur * (cmp ? 24 : (b6 ? 28 : (f16 ? 12 : (by * bx == 16 ? 16 : 20))));
   const size_t x = (size_t)nbw * 4 * 2 * 16 * 64;
-  const size_t rimg = (size_t)(bz + 2) * (by + 2) * (bx + 2) * (bz == 8 ? 24 : 20);
+  const size_t rimg = (size_t)(bz + (cmp ? 0 : 2)) * (by + 2) * (bx + 2) * (cmp ? 20 : (bz == 8 ? 24 : 20));
   return (128 + std::max(u, x) + rimg) * sizeof(float);       // R behind max(U, exchange): see conv_wino_p_kernel
 }
 
@@ -1091,9 +1110,13 @@ hipError_t launch_wino_b6_repack(const float *wwino, float *w6, long long n_floa
 }
 
 // can this layer run the six-term bf16 form (wfrag = pack_wino_b6 fragments, a.f16 = 2)?  Two-tile table-driven kernel only.
-bool conv_wino_b6_ok(int bz, int by, int bx, int Co) {
-  return bz != 8 && conv_wino_tile_ok(bz, by, bx) && conv_wino_nbw(bz, Co) == 2 && conv_wino_p_lds(bz, by, bx, false, 2, true) <= 160 * 1024 &&
-         !cm::diag_env("CM_NO_WINO_P");
+bool conv_wino_b6_ok(int bz, int by, int bx, int Co, int Zo) {
+  if (cm::diag_env("CM_NO_WINO_P") || !conv_wino_tile_ok(bz, by, bx)) return false;
+  const int nbw = conv_wino_nbw(bz, Co);
+  // two-tile layers (one workgroup per CU), or the full-resolution tile whose planes span the whole frame axis (compact LDS
+  // form: the padding planes have no rows, two workgroups per CU)
+  if (bz != 8) return nbw == 2 && conv_wino_p_lds(bz, by, bx, false, 2, true) <= 160 * 1024;
+  return nbw == 1 && by == 4 && bx == 4 && Zo == 8 && 2 * conv_wino_p_lds(bz, by, bx, false, 1, true) <= 160 * 1024 && !cm::diag_env("CM_NO_WINO_B6_FULL");
 }
 
 hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
@@ -1102,7 +1125,7 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
   if (!conv_wino_ok(a)) return hipErrorInvalidValue;
   const int nbw = conv_wino_nbw(a.bz, a.Co);
   const bool b6 = a.f16 == 2;
-  if (b6 && (f16 || !conv_wino_b6_ok(a.bz, a.by, a.bx, a.Co))) return hipErrorInvalidValue;
+  if (b6 && (f16 || !conv_wino_b6_ok(a.bz, a.by, a.bx, a.Co, a.Zo))) return hipErrorInvalidValue;
   static const bool no_p = cm::diag_env("CM_NO_WINO_P") != nullptr;
 #define CM_WINO_ATTR(KERNEL)                                                                        \
     static bool attr_set[64] = {false};                                                             \
@@ -1120,13 +1143,15 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
   // show the SIMD 83 % busy (58 % matrix, 24 % other vector instructions) while two workgroups are resident -- and its static
   // sample lanes balance worse (85 vs 79 us).  CM_WINO_P=1 under CM_DIAG forces it everywhere for A/B runs.
   static const bool all_p = cm::diag_env("CM_WINO_P") != nullptr;
-  if (conv_wino_two_step(a.bz, a.by, a.bx, f16, nbw) && !no_p && (nbw == 2 || all_p)) {
+  if (conv_wino_two_step(a.bz, a.by, a.bx, f16, nbw) && !no_p && (nbw == 2 || all_p || b6)) {
     const size_t ldsp = conv_wino_p_lds(a.bz, a.by, a.bx, f16, nbw, b6);
     const int ntp = a.ntz * a.nty * a.ntx, nz = (a.Co + 31) / 32 / nbw;
     const int per_cu = (nbw == 1 && 2 * ldsp <= 160 * 1024) ? 2 : 1;
     const int slots = wino_cu_count() * per_cu;
     static const int g_force = cm::diag_env("CM_WINO_G") ? atoi(cm::diag_env("CM_WINO_G")) : 0;
-    const int G = g_force > 0 ? std::min(a.B, g_force) : std::max(1, std::min(a.B, slots / std::max(1, ntp * nz)));
+    // (the full-resolution six-term form runs one tile per workgroup: the persistent loop's static sample lanes balance
+    //  worse than the hardware's own workgroup order on its 3.4-round launches)
+    const int G = g_force > 0 ? std::min(a.B, g_force) : (b6 && nbw == 1) ? a.B : std::max(1, std::min(a.B, slots / std::max(1, ntp * nz)));
     WinoTabs tb;
     hipError_t et = wino_tabs_get(a, 256 * nbw, &tb);
     if (et != hipSuccess) return et;
@@ -1142,6 +1167,11 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
     if (a.s2w) CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, F, NB, true>), THREADS)                \
     CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, F, NB, false>), THREADS)                          \
   }
+#define CM_WINO_PGO61(Z, PY_, PX_, THREADS)                                                         \
+  {                                                                                                 \
+    if (a.s2w) CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, 1, true, true>), THREADS)       \
+    CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, 1, false, true>), THREADS)                 \
+  }
 #define CM_WINO_PGO6(Z, PY_, PX_, THREADS)                                                          \
   {                                                                                                 \
     if (a.s2w) CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, 2, true, true>), THREADS)       \
@@ -1155,7 +1185,10 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
         if (nbw == 2) CM_WINO_PGO(z, py, px, false, 2, 512)                                         \
       }                                                                                             \
       if (f16) CM_WINO_PGO(z, py, px, true, 1, 256)                                                 \
-      if constexpr (z == 8 && py == 2 && px == 2) CM_WINO_PGO(z, py, px, false, 1, 256)             \
+      if constexpr (z == 8 && py == 2 && px == 2) {                                                 \
+        if (b6) CM_WINO_PGO61(z, py, px, 256)                                                       \
+        CM_WINO_PGO(z, py, px, false, 1, 256)                                                       \
+      }                                                                                             \
     }
     CM_WINO_TILES(X)
 #undef X

@@ -127,7 +127,7 @@ int conv_wino_nbw(int bz, int Co);
 // f16: a.wfrag holds the f16 packing (3 groups per chunk and wave, 8 halves per lane): fp32 accumulate, f16 operands
 hipError_t launch_conv_wino(const ConvArgs &a, bool f16, hipStream_t st);
 // six-term bf16 form (a.f16 = 2, wfrag = pack_wino_b6 fragments): two-tile table-driven kernel only
-bool conv_wino_b6_ok(int bz, int by, int bx, int Co);
+bool conv_wino_b6_ok(int bz, int by, int bx, int Co, int Zo);
 // its split fragments from the fp32 Winograd fragments (n_floats of them), e.g. after an optimizer step
 hipError_t launch_wino_b6_repack(const float *wwino, float *w6, long long n_floats, hipStream_t st);
 // Weight gradient in the Winograd domain (same tiles): partials part[G][ncb][nkb][3][16][32 ci][32 co], then G^T dU G

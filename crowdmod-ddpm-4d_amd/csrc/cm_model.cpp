@@ -935,7 +935,7 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     {
       int wz = 0, wy = 0, wx = 0;
       if (m->precision != CM_PRECISION_F16 && !cm::diag_env("CM_NO_WINO_B6") && cm::conv_wino_pick(s.out->Z, s.out->Y, s.out->X, &wz, &wy, &wx) &&
-          cm::conv_wino_b6_ok(wz, wy, wx, s.Co) && upload(m, pack_wino_b6(ww), &op.d_wwino_b6))
+          cm::conv_wino_b6_ok(wz, wy, wx, s.Co, s.out->Z) && upload(m, pack_wino_b6(ww), &op.d_wwino_b6))
         return 1;
     }
     // reduced-precision plan: the direct f16 kernel replaces the Winograd one where its tiles fit (no transforms to pay for
@@ -1460,7 +1460,7 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     const bool f16 = op.d_wwino16 && !m->train_fwd;
     ca.wfrag = f16 ? op.d_wwino16 : op.d_wwino;
     // two-tile layers, fp32 plan, inference forward: six-term bf16 products (same tile geometry as the plan picked)
-    if (!f16 && op.d_wwino_b6 && !m->train_fwd && cm::conv_wino_b6_ok(ca.bz, ca.by, ca.bx, ca.Co)) { ca.wfrag = op.d_wwino_b6; ca.f16 = 2; }
+    if (!f16 && op.d_wwino_b6 && !m->train_fwd && cm::conv_wino_b6_ok(ca.bz, ca.by, ca.bx, ca.Co, ca.Zo)) { ca.wfrag = op.d_wwino_b6; ca.f16 = 2; }
     CM_HIP(cm::launch_conv_wino(ca, f16, st));
   } else if (op.first_k) {
     CM_HIP(cm::launch_conv_first(ca, op.first_cin, op.d_wfirst, st));
