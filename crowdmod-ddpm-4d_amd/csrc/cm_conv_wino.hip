@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
   constexpr int CS = 16, S = CMP ? 24 : (B6 ? 28 : (F16 ? 12 : (SWZ ? CS : CS + 4)));   // B6: three bf16 planes of 8 dwords (+ 4 pad)
   constexpr int RYH = 2 * PY + 2, RXH = 2 * PX + 2, RV = HZ * RYH * RXH, RS_ = CMP ? 20 : (BZ == 8 ? 24 : 20);
   constexpr int PLV = RYH * RXH, RVC = CMP ? BZ * PLV : RV, RV0 = CMP ? PLV : 0;   // R voxels kept, first kept halo voxel
-  constexpr int RK = (RV * 4 + NT - 1) / NT;
+  constexpr int RK = ((CMP ? BZ * RYH * RXH : RV) * 4 + NT - 1) / NT;   // step-A rounds per thread (CMP: the real planes only)
   constexpr int NITEMS = HZ * NP * (CS / 4);
   static_assert(NITEMS <= 256, "one staging item per thread");
   constexpr int USZ = 16 * URC * S, XSZ = NBW * 4 * 2 * 16 * 64;
@@ -580,7 +580,12 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
   int asoff[RK];
   unsigned aok = 0;
 #pragma unroll
-  for (int k = 0; k < RK; ++k) asoff[k] = tabA[(p * RK + k) * (NT / 4) + (tid >> 2)];
+  for (int k = 0; k < RK; ++k) {
+    // (the table is laid out for the full halo box, RKT rounds of NT / 4 voxels; CMP starts at the first real plane)
+    constexpr int RKT = (RV * 4 + NT - 1) / NT;
+    const int v = (tid >> 2) + (NT / 4) * k + RV0;
+    asoff[k] = v < RKT * (NT / 4) ? tabA[p * RKT * (NT / 4) + v] : -1;
+  }
 #pragma unroll
   for (int k = 0; k < RK; ++k) {
     aok |= (asoff[k] >= 0 ? 1u : 0u) << k;
@@ -591,8 +596,10 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
   // both halves of the workgroup take every item: waves 0-3 compute the frequency columns xi_x in {0, 1}, waves 4-7 {2, 3}
   // (eight of the sixteen components each; the half is wave-uniform, so nothing is computed twice) -- the transform runs on
   // all eight waves instead of four, with half the arithmetic per thread
-  constexpr bool HX2 = NT == 512 && NITEMS <= 256;
-  const int itid = HX2 ? (tid & 255) : tid, hf = HX2 ? wv8 >> 2 : 0;
+  // (CMP: the 128 items of the real planes, waves 0-1 / 2-3)
+  constexpr bool HX2 = (NT == 512 && NITEMS <= 256) || CMP;
+  constexpr int HXM = CMP ? 127 : 255;
+  const int itid = HX2 ? (tid & HXM) + (CMP ? 4 * NP : 0) : tid, hf = HX2 ? (CMP ? wv8 >> 1 : wv8 >> 2) : 0;
   const int it = itid < NITEMS ? itid : 0;
   const int quad = it & 3, patch = (it >> 2) % NP, zi = it / (4 * NP);
   const bool stager = itid < NITEMS && !(CMP && (zi == 0 || zi == HZ - 1));   // CMP: padding planes are never transformed
@@ -686,7 +693,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
       if (a.gn && a.silu && !a.pm) {
 #pragma unroll
         for (int k = 0; k < RK; ++k) {
-          const int v = (tid >> 2) + (NT / 4) * k;
+          const int v = (tid >> 2) + (NT / 4) * k + RV0;
           f32x4 w = ald[k] * sc1 + sh1;
           w[0] = silu_w(w[0]); w[1] = silu_w(w[1]); w[2] = silu_w(w[2]); w[3] = silu_w(w[3]);
           if (!((aok >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -695,7 +702,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
       } else {
 #pragma unroll
         for (int k = 0; k < RK; ++k) {
-          const int v = (tid >> 2) + (NT / 4) * k;
+          const int v = (tid >> 2) + (NT / 4) * k + RV0;
           f32x4 w = ald[k];
           if (a.gn) {
             w = w * sc1 + sh1;
