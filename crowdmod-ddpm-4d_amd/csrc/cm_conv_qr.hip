@@ -28,6 +28,8 @@ namespace cm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef __bf16 bf16x8q __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4q __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float silu_q(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // Chan et al. pairwise combination of (n, mean, M2) triples (same arithmetic as cm_misc.hip)
@@ -325,10 +327,14 @@ __global__ __launch_bounds__(512, 2) void conv_qr_kernel(const QrArgs a) {
 // with no workgroup barrier between the table set-up and the final reduction: LDS operations of one wave execute in order,
 // so a slice written by the wave is visible to its own later reads.  The two waves of a SIMD de-phase by themselves: one
 // stages / waits for memory while the other multiplies.
-template <int MBP, bool SKIP>
+// B6: fp32 products from exact three-way bf16 splits (cm_conv_ups.hip explains the arithmetic).  A step is 16 channels (the
+// wave's range padded with zeros to whole steps), its slice holds three bf16 planes per voxel (single-buffered: the waves
+// have one or two steps), a tap is 4 (plane, z tap) pairs x 6 v_mfma_f32_32x32x16_bf16.  The fused skip conv stays fp32.
+template <int MBP, bool SKIP, bool B6 = false>
 __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
   constexpr int MB = 2 * MBP;
-  constexpr int SS = 12;                           // slice row stride in floats: 8 channels + 4 pad (conflict-free 16-byte reads)
+  constexpr int SS = B6 ? 28 : 12;                 // slice row stride in floats: 8 channels + 4 pad (conflict-free 16-byte reads); B6: 3 x 8 + 4
+  constexpr int NBUF = B6 ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
   float *gst = lds + HVp;
   float *red = gst + 8 * 64;
   float *slices = red + 2 * MB * 8 * 32;
-  float *sl0 = slices + (size_t)wave * 2 * HVp * SS;
+  float *sl0 = slices + (size_t)wave * NBUF * HVp * SS;
 
   if (tid < HV) {
     const int pl = tid / HYX, rem = tid - pl * HYX, hy = rem / HX, hx = rem - hy * HX;
@@ -378,19 +384,23 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
     grstd = rsqrtf(S2 / N + a.eps);
   }
   // ---- staging items of a step: (halo voxel, channel quad of the step's 8 channels); item = lane + 64 k --------------------
-  constexpr int NIT = 6;                           // items per lane: 2 HV / 64 <= 6 (HV <= 192: conv_qr2_ok)
-  const int nit = (2 * HV + 63) >> 6;
+  constexpr int NIT = B6 ? 9 : 6;                  // items per lane: 2 HV / 64 <= 6 (HV <= 192: conv_qr2_ok); B6: 4 HV / 64 <= 9
+  constexpr int QSH = B6 ? 2 : 1;                  // log2 channel quads per step
+  const int nit = ((HV << QSH) + 63) >> 6;
   int ioff[NIT];                                     // source voxel offset (-1: padding / beyond the box)
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
-    const int it = lane + 64 * k, hv = it >> 1;
+    const int it = lane + 64 * k, hv = it >> QSH;
     ioff[k] = (k < nit && hv < HV) ? hvinfo[hv] : -1;
   }
-  const int qq = lane & 1;                          // (64 k is even: the quad of an item does not depend on k)
-  const int nsteps = cw >> 3;
+  const int qq = lane & ((1 << QSH) - 1);           // (64 k is a multiple of the quad count: the quad of an item does not depend on k)
+  const int nsteps = B6 ? (cw + 15) >> 4 : cw >> 3;
+  bool cq_ok = true;                                // B6: this lane's quad of the step lies inside the wave's channel range
   f32x4 ld[NIT], ldg, ldb;                            // halo loads of the next step and its affine rows, in flight
   auto issue = [&](int s) {
-    const int c = c0w + 8 * s + 4 * qq;
+    const int cl = (B6 ? 16 : 8) * s + 4 * qq;
+    cq_ok = cl < cw;
+    const int c = c0w + (cq_ok ? cl : 0);
     ldg = *reinterpret_cast<const f32x4 *>(a.gamma + c);
     ldb = *reinterpret_cast<const f32x4 *>(a.beta + c);
     const bool from0 = c < a.C0;
@@ -402,15 +412,27 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
   };
   auto stage = [&](int s) {
     const f32x4 sc = ldg * grstd, sh = ldb - gmean * sc;
-    float *dst = sl0 + (size_t)(s & 1) * HVp * SS + 4 * qq;
+    float *dst = sl0 + (size_t)(B6 ? 0 : (s & 1)) * HVp * SS + (B6 ? 2 : 4) * qq;
 #pragma unroll
     for (int k = 0; k < NIT; ++k)
       if (k < nit) {
-        const int it = lane + 64 * k, hv = it >> 1;
+        const int it = lane + 64 * k, hv = it >> QSH;
         f32x4 w = ld[k] * sc + sh;
         if (a.silu) { w[0] = silu_q(w[0]); w[1] = silu_q(w[1]); w[2] = silu_q(w[2]); w[3] = silu_q(w[3]); }
-        if (ioff[k] < 0) w = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (hv < HV) *reinterpret_cast<f32x4 *>(dst + (size_t)hv * SS) = w;
+        if (ioff[k] < 0 || !cq_ok) w = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (B6) {
+          if (hv < HV) {
+            f32x4 rem = w;
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) {
+              const bf16x4q hb = {(__bf16)rem[0], (__bf16)rem[1], (__bf16)rem[2], (__bf16)rem[3]};
+              *reinterpret_cast<bf16x4q *>(dst + (size_t)hv * SS + 8 * tm) = hb;
+              if (tm < 2) rem = rem - f32x4{(float)hb[0], (float)hb[1], (float)hb[2], (float)hb[3]};   // exact remainder
+            }
+          }
+        } else {
+          if (hv < HV) *reinterpret_cast<f32x4 *>(dst + (size_t)hv * SS) = w;
+        }
       }
   };
   issue(0);
@@ -429,6 +451,74 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
   for (int i = 0; i < MB; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  if constexpr (B6) {
+    // split fragments [n tile][wave][step][tap 9][dz][term][lane] 16 B (pack_qr_b6)
+    const int ngw = nsteps * 9;
+    const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.wq6) + ((size_t)(nt * 8 + wave) * ngw) * 9 * 64 + lane;
+    constexpr int RD = 1;                           // (must divide 9: a slot is tap % RD in every step; 3 would be 108 registers)
+    f32x4 bw[RD][3][3];
+#pragma unroll
+    for (int t = 0; t < RD; ++t)
+      if (t < ngw) {
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+          for (int tm = 0; tm < 3; ++tm) bw[t][dz][tm] = wq[(((size_t)t * 3 + dz) * 3 + tm) * 64];
+      }
+    stage(0);
+    if (nsteps > 1) issue(1);
+    for (int s = 0; s < nsteps; ++s) {
+      const float *Asl = sl0;
+      f32x4 a0[2][MBP][3], a1[2][MBP][3];             // (current | next tap) x row block x term
+#pragma unroll
+      for (int j = 0; j < MBP; ++j)
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) {
+          a0[0][j][tm] = *reinterpret_cast<const f32x4 *>(Asl + abase[j] + 8 * tm);
+          a1[0][j][tm] = *reinterpret_cast<const f32x4 *>(Asl + abase[j] + HYX * SS + 8 * tm);
+        }
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const int gl = s * 9 + t9;
+        if (t9 + 1 < 9) {
+          const int dy = (t9 + 1) / 3, dx = (t9 + 1) - 3 * dy;
+          const int toff = (dy * HX + dx) * SS;
+#pragma unroll
+          for (int j = 0; j < MBP; ++j)
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) {
+              a0[(t9 + 1) & 1][j][tm] = *reinterpret_cast<const f32x4 *>(Asl + abase[j] + toff + 8 * tm);
+              a1[(t9 + 1) & 1][j][tm] = *reinterpret_cast<const f32x4 *>(Asl + abase[j] + toff + HYX * SS + 8 * tm);
+            }
+        }
+        // (A term, B term), small products first: hi = 0, mid = 1, lo = 2
+        constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+        auto six = [&](f32x16 &d, const f32x4 (&av)[3], const f32x4 (&wv)[3]) {
+#pragma unroll
+          for (int u = 0; u < 6; ++u)
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8q, av[TA[u]]), __builtin_bit_cast(bf16x8q, wv[TB[u]]), d, 0, 0, 0);
+        };
+#pragma unroll
+        for (int j = 0; j < MBP; ++j) {
+          six(acc[j], a0[t9 & 1][j], bw[t9 % RD][1]);
+          six(acc[MBP + j], a0[t9 & 1][j], bw[t9 % RD][0]);
+          six(acc[j], a1[t9 & 1][j], bw[t9 % RD][2]);
+          six(acc[MBP + j], a1[t9 & 1][j], bw[t9 % RD][1]);
+        }
+        if (gl + RD < ngw) {
+#pragma unroll
+          for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) bw[t9 % RD][dz][tm] = wq[(((size_t)(gl + RD) * 3 + dz) * 3 + tm) * 64];
+        }
+        asm volatile("" ::: "memory");
+      }
+      if (s + 1 < nsteps) {
+        stage(s + 1);
+        if (s + 2 < nsteps) issue(s + 2);
+      }
+    }
+  } else {
   const int K8 = Ci >> 3, ng = 9 * K8;
   const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.wq) + ((size_t)nt * ng + (size_t)wave * nsteps * 9) * 3 * 64 + lane;
   // weight ring: RD in-plane taps deep (9 = a whole step ahead where the registers allow it); slot = tap % RD is static, a
@@ -491,6 +581,7 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
       stage(s + 1);
       if (s + 2 < nsteps) issue(s + 2);
     }
+  }
   }
   if constexpr (SKIP) {
     const int Cs2 = a.s2C0 + a.s2C1, ngs = Cs2 >> 3;
@@ -599,10 +690,40 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
   }
 }
 
-size_t conv_qr2_lds(const QrArgs &a, int MBP) {
+// split fragments of the six-term form from the fp32 fragments (pack_qr order [n tile][g = k8 * 9 + t9][dz][lane][4]) into
+// pack_qr_b6 order; one thread per weight.  Padding slots of the last step of a wave stay zero (never written).
+__global__ __launch_bounds__(256) void qr_b6_repack_kernel(const float *__restrict__ wq, unsigned short *__restrict__ w6, long long n, int Ci) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ng = 9 * (Ci >> 3), cw = Ci >> 3, nsw = (cw + 15) >> 4;
+  const int jj = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  long long q = i >> 8;
+  const int dz = (int)(q % 3); q /= 3;
+  const int g = (int)(q % ng);
+  const int nt = (int)(q / ng);
+  const int k8 = g / 9, t9 = g - 9 * k8, ci = 8 * k8 + 4 * (lane >> 5) + jj, r = lane & 31;
+  const int wv = ci / cw, cl = ci - wv * cw, st = cl >> 4, hd = (cl >> 3) & 1, j = cl & 7;
+  unsigned short *dst = w6 + ((((((size_t)(nt * 8 + wv) * nsw + st) * 9 + t9) * 3 + dz) * 3) * 64 + 32 * hd + r) * 8 + j;
+  float rem = wq[i];
+#pragma unroll
+  for (int tm = 0; tm < 3; ++tm) {
+    const __bf16 hb = (__bf16)rem;
+    dst[(size_t)tm * 64 * 8] = __builtin_bit_cast(unsigned short, hb);
+    rem -= (float)hb;
+  }
+}
+
+hipError_t launch_qr_b6_repack(const float *wq, float *wq6, long long n_floats, int Ci, hipStream_t st) {
+  if (n_floats <= 0 || Ci % 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(qr_b6_repack_kernel, dim3((unsigned)((n_floats + 255) / 256)), dim3(256), 0, st, wq, reinterpret_cast<unsigned short *>(wq6),
+                     n_floats, Ci);
+  return hipGetLastError();
+}
+
+size_t conv_qr2_lds(const QrArgs &a, int MBP, bool b6) {
   const int HV = 2 * (a.Y + 2) * (a.X + 2), HVp = (HV + 3) & ~3, MB = 2 * MBP;
   const size_t head = (size_t)HVp + 8 * 64 + 2 * MB * 8 * 32;
-  const size_t sl = (size_t)8 * 2 * HVp * 12, pbuf = (size_t)8 * MB * 4 * 64 * 4;
+  const size_t sl = b6 ? (size_t)8 * HVp * 28 : (size_t)8 * 2 * HVp * 12, pbuf = (size_t)8 * MB * 4 * 64 * 4;
   return (head + std::max(sl, pbuf)) * sizeof(float);
 }
 
@@ -610,7 +731,13 @@ size_t conv_qr2_lds(const QrArgs &a, int MBP) {
 bool conv_qr2_ok(const QrArgs &a) {
   const int Ci = a.C0 + a.C1;
   return a.gamma && a.groups == 8 && Ci % 64 == 0 && Ci / 8 <= 32 && a.C0 % 4 == 0 && a.C1 % 4 == 0 && 2 * (a.Y + 2) * (a.X + 2) <= 192 &&
-         conv_qr2_lds(a, a.Y * a.X > 32 ? 2 : 1) <= 160 * 1024;
+         conv_qr2_lds(a, a.Y * a.X > 32 ? 2 : 1, false) <= 160 * 1024;
+}
+
+// the six-term bf16 form of v2: split fragments present, <= 9 staging items per lane, its single-buffered slices fit
+bool conv_qr2_b6_ok(const QrArgs &a) {
+  return a.wq6 && conv_qr2_ok(a) && a.Y * a.X <= 32 && 4 * 2 * (a.Y + 2) * (a.X + 2) <= 64 * 9 &&   // (two row blocks per plane spill: fp32 form)
+         conv_qr2_lds(a, a.Y * a.X > 32 ? 2 : 1, true) <= 160 * 1024;
 }
 
 size_t conv_qr_lds(const QrArgs &a, int MBP) {
@@ -638,7 +765,8 @@ hipError_t launch_conv_qr(const QrArgs &a_in, hipStream_t st) {
   const int MBP = a.Y * a.X > 32 ? 2 : 1;
   static const bool no_v2 = cm::diag_env("CM_NO_QR2") != nullptr;
   const bool v2 = conv_qr2_ok(a) && !no_v2;
-  const size_t lds = v2 ? conv_qr2_lds(a, MBP) : conv_qr_lds(a, MBP);
+  const bool b6 = v2 && conv_qr2_b6_ok(a);
+  const size_t lds = v2 ? conv_qr2_lds(a, MBP, b6) : conv_qr_lds(a, MBP);
   const dim3 grid((unsigned)a.B, (unsigned)(a.Co / 32));
 #define CM_QR_GO(KERNEL)                                                                            \
   {                                                                                                 \
@@ -652,6 +780,14 @@ hipError_t launch_conv_qr(const QrArgs &a_in, hipStream_t st) {
     }                                                                                               \
     hipLaunchKernelGGL(KERNEL, grid, dim3(512), lds, st, a);                                        \
     return hipGetLastError();                                                                       \
+  }
+  if (b6) {
+    if (MBP == 1) {
+      if (a.s2w) CM_QR_GO((conv_qr2_kernel<1, true, true>))
+      CM_QR_GO((conv_qr2_kernel<1, false, true>))
+    }
+    if (a.s2w) CM_QR_GO((conv_qr2_kernel<2, true, true>))
+    CM_QR_GO((conv_qr2_kernel<2, false, true>))
   }
   if (v2) {
     if (MBP == 1) {

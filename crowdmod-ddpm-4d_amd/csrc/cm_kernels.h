@@ -151,6 +151,7 @@ struct QrArgs {
   float eps;
   int silu;
   float *gn_out;                 // optional [B][2][C0 + C1] copy of the folded scale / shift rows
+  const float *wq6;              // optional: the same weights as exact bf16 x 3 splits (pack_qr_b6) -> six-term products in conv_qr2
   const float *wq;               // [Co / 32][g = k8 * 9 + dy * 3 + dx][dz][64 lanes][4]: W[co = 32 nt + lane % 32][ci = 8 k8 + 4 (lane / 32) + jj][(dz, dy, dx)]
   const float *bias;
   const float *temb;
@@ -168,6 +169,9 @@ struct QrArgs {
   int qshift;                    // (set by the launcher) log2 of the staging's channel-quad lane count
 };
 bool conv_qr_ok(const QrArgs &a);
+bool conv_qr2_b6_ok(const QrArgs &a);
+// split fragments of conv_qr2's six-term form from the fp32 fragments `wq` (n_floats of them; Ci input channels), e.g. after an optimizer step
+hipError_t launch_qr_b6_repack(const float *wq, float *wq6, long long n_floats, int Ci, hipStream_t st);
 hipError_t launch_conv_qr(const QrArgs &a, hipStream_t st);
 
 // Direct 3x3x3 stride-1 conv with f16 operands (cm_conv_f16.hip; reduced-precision plan): a.bz/by/bx = output box (divides the

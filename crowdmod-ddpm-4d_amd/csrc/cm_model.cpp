@@ -122,6 +122,8 @@ struct Op {
   float *d_w16d = nullptr, *d_w16d_skip = nullptr;
   bool qr = false;          // whole-sample kernel of the lowest resolution (cm_conv_qr.hip), inference plan
   float *d_wqr = nullptr, *d_wqr_skip = nullptr;
+  float *d_wqr_b6 = nullptr;    // exact bf16 x 3 split of d_wqr for the six-term form of conv_qr2 (pack_qr_b6)
+  long long wqr_floats = 0;
   bool qr_consumer = false; // OP_GNFIN whose only consumer is a qr conv: that kernel finalises the statistics itself
   bool first_k = false;     // the UNet's first conv on its dedicated kernel (cm_conv_io.hip)
   int first_cin = 4;        //   input channels it contracts per tap: 4 (C <= 4) or 8
@@ -793,6 +795,30 @@ std::vector<float> pack_qr(const std::vector<float> &wi, int Co, int Ci) {
           }
   return out;
 }
+// Six-term bf16 form of conv_qr2 (B6): the fp32 fragments of pack_qr split exactly into three bf16 terms and regrouped by wave
+// (wave w owns the channels [w Ci/8, (w+1) Ci/8), padded with zeros to whole 16-channel steps):
+// [Co/32][wave 8][step][tap 9][dz][term][lane][8 bf16], ci = wave * Ci/8 + 16 step + 8 hh + j.  `wq` is pack_qr's output.
+// The device re-derives it after an optimizer step with the same index arithmetic (qr_b6_repack_kernel).
+std::vector<float> pack_qr_b6(const std::vector<float> &wq, int Co, int Ci) {
+  const int ntn = Co / 32, K8 = Ci / 8, ng = 9 * K8, cw = Ci / 8, nsw = (cw + 15) / 16;
+  std::vector<uint16_t> out((size_t)ntn * 8 * nsw * 9 * 3 * 3 * 64 * 8, 0);
+  for (size_t i = 0; i < wq.size(); ++i) {
+    const int jj = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    size_t q = i >> 8;
+    const int dz = (int)(q % 3); q /= 3;
+    const int g = (int)(q % ng);
+    const int nt = (int)(q / ng);
+    const int k8 = g / 9, t9 = g % 9, ci = 8 * k8 + 4 * (lane >> 5) + jj, r = lane & 31;
+    const int wv = ci / cw, cl = ci % cw, st = cl / 16, hd = (cl % 16) / 8, j = cl % 8;
+    uint16_t t3[3];
+    bf16_split3(wq[i], t3);
+    for (int tm = 0; tm < 3; ++tm)
+      out[(((((((size_t)(nt * 8 + wv) * nsw + st) * 9 + t9) * 3 + dz) * 3 + tm) * 64) + 32 * hd + r) * 8 + j] = t3[tm];
+  }
+  std::vector<float> packed(out.size() / 2);
+  std::memcpy(packed.data(), out.data(), out.size() * 2);
+  return packed;
+}
 // its fused 1x1x1 skip weights: [Co/32][Cs/8][lane][jj]; `w2` is [Co][Cs]
 std::vector<float> pack_qr_skip(const float *w2, int Co, int Cs) {
   const int ntn = Co / 32, ngs = Cs / 8;
@@ -1029,7 +1055,13 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     q.C0 = a.C0; q.C1 = a.C1; q.Co = s.Co; q.Y = s.out->Y; q.X = s.out->X; q.groups = GN_GROUPS; q.gamma = m->ops[op.gn_op].gamma;
     if (op.d_s2w) { q.s2w = op.d_s2w; q.s2C0 = s.skip0->C; q.s2C1 = s.skip1 ? s.skip1->C : 0; }
     if (cm::conv_qr_ok(q)) {
-      if (upload(m, pack_qr(wi, s.Co, Ci_ref), &op.d_wqr)) return 1;
+      {
+        const std::vector<float> wq = pack_qr(wi, s.Co, Ci_ref);
+        if (upload(m, wq, &op.d_wqr)) return 1;
+        op.wqr_floats = (long long)wq.size();
+        if (m->precision != CM_PRECISION_F16 && Ci_ref % 64 == 0 && !cm::diag_env("CM_NO_QR_B6") && upload(m, pack_qr_b6(wq, s.Co, Ci_ref), &op.d_wqr_b6))
+          return 1;
+      }
       if (op.d_s2w) {
         const Param &w2 = P(m, s.skip_w);
         if (upload(m, pack_qr_skip(w2.host.data(), s.Co, (int)w2.shape[1]), &op.d_wqr_skip)) return 1;
@@ -1303,6 +1335,7 @@ int run_conv_qr(cm_model *m, Op &op, int B, hipStream_t st, int b0) {
   if (g0->C != ca.C0 || (g1 ? g1->C : 0) != ca.C1) return fail("quarter-resolution conv %s: statistics and sources disagree", op.label.c_str());
   q.gamma = gop.gamma; q.beta = gop.beta; q.groups = GN_GROUPS; q.eps = GN_EPS; q.silu = ca.silu;
   q.wq = op.d_wqr; q.bias = ca.bias;
+  q.wq6 = op.d_wqr_b6;
   q.temb = ca.temb; q.temb_stride = ca.temb_stride; q.tidx = ca.tidx + b0;
   q.resid = ca.resid ? ca.resid + (size_t)b0 * V * ca.res_cs : nullptr; q.res_cs = ca.res_cs;
   if (op.d_wqr_skip) {
