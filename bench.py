@@ -313,7 +313,11 @@ def main():
         conv_s = un[0] / 1e3                              # (== ms[0] with one lane)
         ach = conv3_flops / conv_s / 1e12 if conv_s > 0 else 0.0
         exe = conv3_exec / conv_s / 1e12 if conv_s > 0 else 0.0
-        peak = FP32_MFMA_PEAK_TFLOPS if a.dtype == "f32" else F16_MFMA_PEAK_TFLOPS
+        # matrix-pipe roof of THIS instruction mix: the time the issued instructions need at their peaks (fp32 instructions at
+        # 157.3 TF, 16-bit-operand instructions at 2500 TF -- a six-term fp32 product issues six of the latter) over the class time
+        i32, i16 = model.denoiser.conv3_issue_flops(nb)
+        pipe_s = steps * (i32 / (FP32_MFMA_PEAK_TFLOPS * 1e12) + i16 / (F16_MFMA_PEAK_TFLOPS * 1e12))
+        peak = conv3_exec / pipe_s / 1e12 if pipe_s > 0 else FP32_MFMA_PEAK_TFLOPS
         roofline = {
             "kernel": "all 3x3x3 conv launches: conv_wino[_p]_kernel (Winograd F(2x2,3x3) over the in-plane axes, full- and "
                       "half-resolution layers), conv_qr2_kernel (whole-sample quarter resolution), conv_ups_kernel (parity-form "
@@ -321,7 +325,15 @@ def main():
                       "conv_smalln_kernel",
             "bound": "mfma", "achieved": exe, "peak": peak, "unit": "TFLOP/s",
             "frac": exe / peak, "traffic": hbm_traffic(),
-            "algorithmic_tflops": ach, "algorithmic_frac": ach / peak,
+            "peak_is": "fp32-equivalent TFLOP/s this launch mix would reach with the matrix pipe never idle: executed fp32-equivalent "
+                       "FLOPs / (FLOPs issued as v_mfma_f32_32x32x2_f32 / %.1f TF + FLOPs issued as v_mfma_f32_32x32x16_{bf16,f16} / "
+                       "%.0f TF); six-term layers issue 6 bf16 products per fp32 product, so `frac` = matrix-pipe busy time at peak "
+                       "rate / measured class time (compare SQ_VALU_MFMA_BUSY_CYCLES in profiles/round3_pmc_summary.csv)"
+                       % (FP32_MFMA_PEAK_TFLOPS, F16_MFMA_PEAK_TFLOPS),
+            "issued_fp32_gflop_per_step": i32 / 1e9, "issued_16bit_gflop_per_step": i16 / 1e9,
+            "matrix_pipe_ms_per_step_at_peak": pipe_s / steps * 1e3,
+            "frac_of_plain_fp32_mfma_peak": exe / FP32_MFMA_PEAK_TFLOPS,
+            "algorithmic_tflops": ach, "algorithmic_frac": ach / FP32_MFMA_PEAK_TFLOPS,
             "launches": int(cnt[0]), "avg_launch_us": ms[0] * 1e3 / max(1, cnt[0]),
             "lanes": lanes_eff, "class_busy_ms": un[0], "sum_of_launch_ms": ms[0],
             "measured_with": "an extra run of the same K steps with HIP events around every launch on its launch stream "
@@ -331,8 +343,10 @@ def main():
                              "duration exists) and recording events from two host threads slows the profiled pass itself by "
                              "~15 %; `value` runs the default two lanes, which is 4-5 % faster than the sum of these launches. "
                              "(CM_PROFILE_LANES=1 profiles the lanes: class time = union of the launch intervals, "
-                             "`class_busy_ms`.)  `achieved` / `frac` count the matrix-core FLOPs actually ISSUED (Winograd, parity and "
-                             "z-split forms issue fewer than the direct form) -- the hardware fraction; `algorithmic_*` counts "
+                             "`class_busy_ms`.)  `achieved` counts the fp32-equivalent matrix-core FLOPs actually EXECUTED (Winograd, "
+                             "parity and z-split forms execute fewer than the direct form); `frac` = achieved / peak is the hardware "
+                             "fraction (`peak_is`); `frac_of_plain_fp32_mfma_peak` prices the same FLOPs against the fp32 instruction's "
+                             "157.3 TF alone and exceeds what a pure-fp32 kernel could reach; `algorithmic_*` counts "
                              "2 x 27 x Ci x Co per voxel as PyTorch counts the reference's nn.Conv3d and can exceed 1 (it "
                              "is the algorithmic saving, not a roof); rocprofv3 --kernel-trace --stats of this command: "
                              "profiles/round3_kernel_stats.csv",
@@ -356,7 +370,10 @@ def main():
                  ("config/ATC_synthetic.yml", (24, 72)): "BASELINE configs[4], one GPU's shard",
                  ("config/ATC.yml", (24, 72)): "BASELINE configs[4] shape"}
         tag = known.get((cfg_name, (res.rows, res.cols)), "not a BASELINE config")
-        wl = "%s sampling on the %dx%d grid, %s matrix-core operands (%s)" % (cfg_name, res.rows, res.cols, a.dtype, tag)
+        opnd = ("fp32 arithmetic (fp32 matrix instructions, and fp32 products built from exact three-way bf16 splits -- six "
+                "v_mfma_f32_32x32x16_bf16 terms, fp32 accumulate -- in the Winograd / quarter-resolution / upsample layers)"
+                if a.dtype == "f32" else "f16 matrix-core operands, fp32 accumulate")
+        wl = "%s sampling on the %dx%d grid, %s (%s)" % (cfg_name, res.rows, res.cols, opnd, tag)
         out = {
             "metric": "denoise-steps/sec (UNet fwd + sampler update) at ATC [B,4,T,H,W]",
             "value": world * steps / elapsed,

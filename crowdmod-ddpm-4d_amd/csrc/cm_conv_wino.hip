@@ -538,6 +538,9 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
 // B6: fp32 products from exact three-way bf16 splits (cm_conv_ups.hip explains the arithmetic): the transformed input is split
 // into hi / mid / lo planes at the U write, the transformed weights arrive pre-split (pack_wino_b6), and 16 channels of a
 // (z tap, component) are six v_mfma_f32_32x32x16_bf16 (192 cycles) instead of eight fp32 instructions (512 cycles).
+#ifndef CM_WINO_ABL
+#define CM_WINO_ABL 0        // compile-time ablations of the six-term chunk loop (experiments only; results are wrong)
+#endif
 template <int BZ, int PY, int PX, bool F16, int NBW, bool SKIP, bool B6 = false>
 __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArgs a, const int *__restrict__ tabA,
                                                                   const int *__restrict__ tabO, int G) {
@@ -689,6 +692,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
       // ---- step A: this chunk's halo voxels -> activated image R ------------------------------------------
       const f32x4 sc1 = scn, sh1 = shn;
       f32x4 pm1 = {1.f, 1.f, 1.f, 1.f};
+      if (!((CM_WINO_ABL & 32) && ch > 0)) {
       if (a.pm) pm1 = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + (ch < n0 ? ch * CS : a.C0 + (ch - n0) * CS) + 4 * aq);
       if (a.gn && a.silu && !a.pm) {
 #pragma unroll
@@ -713,6 +717,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
           if (v >= RV0 && v < RV0 + RVC) *reinterpret_cast<f32x4 *>(R + (v - RV0) * RS_ + 4 * aq) = w;
         }
       }
+      }
       __syncthreads();                          // R complete; every wave is past the previous matrix phase / exchange reads
       if constexpr (CMP) {
         if (ch == 0)                              // the zero block (the previous tile's exchange overwrote it)
@@ -722,7 +727,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
           }
       }
       // ---- step B: B^T d B of the item's 4x4 patch out of R ------------------------------------------------
-      if (stager) {
+      if (stager && !((CM_WINO_ABL & 4) && ch > 0)) {
         f32x4 d[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -777,8 +782,10 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
       }
       __syncthreads();
       // ---- next chunk's loads (possibly the next sample's first chunk): in flight under this matrix phase -----
+#if !(CM_WINO_ABL & 2)
       if (ch + 1 < nchunks) issue(b, ch + 1);
       else if (more_b) issue(b + G, 0);
+#endif
       // ---- matrix phase: NG groups (z tap [, 8-channel half]) x 4 components, A fragments one group ahead -------
       auto aread = [&](int g, f32x4 (&af)[4]) {
         const int dz = F16 ? g : g >> 1, k8 = F16 ? 0 : g & 1;
@@ -804,7 +811,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
           // (A term, B term), small products first: hi = 0, mid = 1, lo = 2
           constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-          for (int u = 0; u < 6; ++u)
+          for (int u = 0; u < ((CM_WINO_ABL & 8) ? 1 : 6); ++u)
             acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af6[sx & 1][TA[u]]),
                                                              __builtin_bit_cast(bf16x8, b6[sx % RD6][TB[u]]), acc[x], 0, 0, 0);
           // refill the slot just read with step sx + RD6 (of this chunk, the next one, or the next sample's first)
@@ -815,10 +822,14 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
             const bool more = !wraps || ch + 1 < nchunks || more_b;
             const int cn = !wraps ? ch : (ch + 1 < nchunks ? ch + 1 : 0);
             const f32x4 *wn = wbase + (size_t)cn * CHS + (size_t)((wraps ? sn - 12 : sn) * 3) * 64;
+#if !(CM_WINO_ABL & 1)
             if (more) {
 #pragma unroll
               for (int tm = 0; tm < 3; ++tm) b6[sx % RD6][tm] = wn[tm * 64];
             }
+#else
+            (void)wn; (void)more;
+#endif
           }
           asm volatile("" ::: "memory");
         }
@@ -855,6 +866,11 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
     // output transform: A^T = (1,1,1,0), (0,1,-1,-1) along x in registers, along y through LDS (16-byte accesses)
     f32x16 t0 = acc[0] + acc[1] + acc[2];
     f32x16 t1 = acc[1] - acc[2] - acc[3];
+    if constexpr ((CM_WINO_ABL & 16) != 0) {      // (ablation: no epilogue; one store keeps the accumulators alive)
+      if (t0[0] + t1[0] == 12345.f) a.out[0] = t0[1];
+      __syncthreads();
+      continue;
+    }
     __syncthreads();                            // U is dead: reuse as the exchange buffer
     f32x4 *const XC = reinterpret_cast<f32x4 *>(U) + (size_t)nbw * (4 * 2 * 4 * 64);   // [wave][blk 2][q 4][lane 64] float4
     {

@@ -1462,7 +1462,7 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     // upsample conv: stage-once parity kernel with its own source tile / statistics slots (f16 operands under the
     // reduced-precision plan's inference forward)
     if (op.d_wups16 && !m->train_fwd) { ca.wfrag = op.d_wups16; ca.wpar_stride = op.wups16_stride; ca.f16 = 1; }
-    else if (op.d_wups_b6 && !m->train_fwd) { ca.wfrag = op.d_wups_b6; ca.wpar_stride = op.wups_b6_stride; ca.f16 = 2; }   // six-term bf16 products
+    else if (op.d_wups_b6 && !(m->train_fwd && cm::diag_env("CM_NO_TRAIN_B6"))) { ca.wfrag = op.d_wups_b6; ca.wpar_stride = op.wups_b6_stride; ca.f16 = 2; }   // six-term bf16 products (training forward too)
     ca.bz = op.ups_tz; ca.by = op.ups_ty; ca.bx = op.ups_tx;
     ca.ntz = ca.Zs / ca.bz; ca.nty = ca.Ys / ca.by; ca.ntx = ca.Xs / ca.bx;
     if (op.stat_act) {
@@ -1493,7 +1493,10 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     const bool f16 = op.d_wwino16 && !m->train_fwd;
     ca.wfrag = f16 ? op.d_wwino16 : op.d_wwino;
     // two-tile layers, fp32 plan, inference forward: six-term bf16 products (same tile geometry as the plan picked)
-    if (!f16 && op.d_wwino_b6 && !m->train_fwd && cm::conv_wino_b6_ok(ca.bz, ca.by, ca.bx, ca.Co, ca.Zo)) { ca.wfrag = op.d_wwino_b6; ca.f16 = 2; }
+    // (the training forward as well: exact splits, fp32 accumulate; its fragments follow every optimizer step)
+    static const bool no_train_b6 = cm::diag_env("CM_NO_TRAIN_B6") != nullptr;
+    if (!f16 && op.d_wwino_b6 && !(m->train_fwd && (no_train_b6 || m->precision == CM_PRECISION_F16)) &&
+        cm::conv_wino_b6_ok(ca.bz, ca.by, ca.bx, ca.Co, ca.Zo)) { ca.wfrag = op.d_wwino_b6; ca.f16 = 2; }
     CM_HIP(cm::launch_conv_wino(ca, f16, st));
   } else if (op.first_k) {
     CM_HIP(cm::launch_conv_first(ca, op.first_cin, op.d_wfirst, st));
@@ -2488,19 +2491,27 @@ int cm_debug_time_conv(cm_model *m, int32_t index, int32_t MB, int32_t bz, int32
 // Matrix-core FLOPs the plan actually EXECUTES per kernel class (<= the algorithmic count: the parity form of the
 // upsample convs runs 8 of 27 taps, the Winograd layers 16 multiplies per 2x2 outputs and z tap instead of 36,
 // computed on whole 32-row blocks and shifted tiles; padding rows of partly filled tiles are counted as executed).
-int cm_model_exec_flops(const cm_model *m, int32_t B, double flops[8]) {
+// `b16`, when given, receives the part of those FLOPs that is issued as 16-bit-operand matrix instructions, in ISSUED FLOPs:
+// a six-term layer (fp32 products from exact three-way bf16 splits) issues six v_mfma_f32_32x32x16_bf16 products per
+// fp32-equivalent product, an f16-plan layer one; `flops` then keeps the part issued as fp32 matrix instructions.
+static int exec_flops_split(const cm_model *m, int32_t B, double flops[8], double *b16) {
   if (!m || !m->finalized || !flops) return fail("model not finalized");
   for (int i = 0; i < 8; ++i) flops[i] = 0;
+  if (b16) for (int i = 0; i < 8; ++i) b16[i] = 0;
+  const bool p16 = m->precision == CM_PRECISION_F16;
   for (const Op &op : m->ops) {
     if (op.kind == OP_ATTN) { flops[op.cls] += 4.0 * op.S * (double)op.S * op.E * B; continue; }
     if (op.kind != OP_CONV || op.skip_if_fused) continue;
+    double mult16 = 0.0;     // 0: fp32 matrix instructions; 1: f16 operands; 6: six-term bf16 products
     const cm::ConvArgs &a = op.ca;
     const double Ci = a.C0 + a.C1;
     double f = op.flops_per_sample;
     if (op.f16d && m->precision == CM_PRECISION_F16) {
       const double tiles = (double)(a.Zo / op.f16d_bz) * (a.Yo / op.f16d_by) * (a.Xo / op.f16d_bx);
       f = tiles * 128.0 * op.f16d_mbw * a.Co * (Ci * 27.0 + (op.d_w16d_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
+      mult16 = 1.0;
     } else if (op.qr) {
+      if (op.d_wqr_b6 && a.Yo * a.Xo <= 32) mult16 = 6.0;
       const double rows = 2.0 * (a.Yo * a.Xo > 32 ? 2 : 1) * 32;        // whole 32-row blocks, one or two per plane
       f = rows * a.Co * (Ci * 18.0 + (op.d_wqr_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
     } else if (op.wino) {
@@ -2509,21 +2520,34 @@ int cm_model_exec_flops(const cm_model *m, int32_t B, double flops[8]) {
         const double tiles = (double)(a.Zo / bz) * ((a.Yo + by - 1) / by) * ((a.Xo + bx - 1) / bx);
         f = tiles * ((a.Co + 31) / 32) * 16.0 * 32 * 32 * Ci * 3 * 2;
         if (op.d_s2w) f += tiles * ((a.Co + 31) / 32) * 4.0 * 32 * 32 * (op.skip0->C + (op.skip1 ? op.skip1->C : 0)) * 2;
+        if (p16 && op.d_wwino16) mult16 = 1.0;
+        else if (!p16 && op.d_wwino_b6 && cm::conv_wino_b6_ok(bz, by, bx, a.Co, a.Zo)) mult16 = 6.0;   // (the fused 1x1 skip conv stays fp32: counted with the layer, a few % of it)
       }
     } else if (a.par && op.ups && (op.d_wups16 || !(op.d_wfrag16 && m->precision == CM_PRECISION_F16))) {
       // whole 32-row blocks per (tile, class); planes tiles that span Z skip one of 2 MBW (row block, z tap) pairs
       const double tiles = (double)(a.Zs / op.ups_tz) * (a.Ys / op.ups_ty) * (a.Xs / op.ups_tx);
       const double pairs = 2.0 * op.ups_mbw - ((op.ups_planes && op.ups_tz == a.Zs) ? 1.0 : 0.0);
       f = tiles * 8.0 * 32.0 * pairs * 4.0 * a.Co * Ci * 2;
+      if (p16 && op.d_wups16) mult16 = 1.0;
+      else if (!p16 && op.d_wups_b6) mult16 = 6.0;
     } else if (a.par) {
+      if (p16 && op.d_wfrag16) mult16 = 1.0;
       f = op.flops_per_sample * 8.0 / 27.0;
       if (cm::conv_zsplit_variant(a, op.MB, op.NB)) f *= 6.0 / 8.0;    // two-plane source: 6 of 8 (row block, z tap) pairs
     } else if (cm::conv_zsplit_variant(a, op.MB, op.NB)) {
       f *= 18.0 / 27.0;                                                // two-plane grid: the padding-plane tap is never issued
     }
-    flops[op.cls] += f * B;
+    if (b16 && mult16 > 0.0) b16[op.cls] += mult16 * f * B;
+    else flops[op.cls] += f * B;
   }
   return 0;
+}
+
+int cm_model_exec_flops(const cm_model *m, int32_t B, double flops[8]) { return exec_flops_split(m, B, flops, nullptr); }
+
+int cm_model_issue_flops(const cm_model *m, int32_t B, double f32[8], double b16[8]) {
+  if (!b16) return fail("null output");
+  return exec_flops_split(m, B, f32, b16);
 }
 
 int cm_model_class_flops(const cm_model *m, int32_t B, double flops[8]) {

@@ -91,6 +91,7 @@ SIGNATURES = {
     "cm_model_cost": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cm_model_class_flops": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double)]),
     "cm_model_exec_flops": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double)]),
+    "cm_model_issue_flops": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cm_frame_metrics": (C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "cm_debug_conv_flags": (C.c_int, [C.c_int32]),
     "cm_debug_conv_count": (C.c_int, [_P, C.POINTER(C.c_int32)]),

@@ -423,6 +423,13 @@ class UNet:
         native.check(native.lib().cm_model_exec_flops(self._handle, B, fl))
         return float(sum(fl))
 
+    def conv3_issue_flops(self, B: int):
+        """(fp32-instruction FLOPs, 16-bit-operand-instruction FLOPs) the 3x3x3 convolutions ISSUE on the matrix cores: a
+        six-term layer (fp32 products from exact three-way bf16 splits) issues six bf16 products per fp32-equivalent one."""
+        f32, b16 = (C.c_double * 8)(), (C.c_double * 8)()
+        native.check(native.lib().cm_model_issue_flops(self._handle, B, f32, b16))
+        return float(f32[0]), float(b16[0])
+
     def conv3_flops(self, B: int) -> float:
         """Algorithmic FLOPs of the 3x3x3 convolutions of one forward at batch B."""
         fl = (C.c_double * 8)()

@@ -211,6 +211,11 @@ int cm_model_class_flops(const cm_model *m, int32_t B, double flops[8]);
 /* Matrix-core FLOPs the plan EXECUTES per class (parity-form upsample convs: 8 of 27 taps; Winograd F(2x2,3x3)
  * layers: 16 multiplies per 2x2 outputs and z tap instead of 36) -- the hardware-utilisation side of the roofline. */
 int cm_model_exec_flops(const cm_model *m, int32_t B, double flops[8]);
+/* The same FLOPs by the matrix instruction that issues them: `f32` = issued as fp32 instructions (v_mfma_f32_32x32x2_f32),
+ * `b16` = ISSUED FLOPs of 16-bit-operand instructions (v_mfma_f32_32x32x16_{bf16,f16}): a six-term layer -- fp32 products
+ * from exact three-way bf16 splits -- issues six of them per fp32-equivalent product, an f16-plan layer one.  The time the
+ * matrix pipe needs at its peaks is f32 / peak_fp32 + b16 / peak_16bit: the numerator of bench.py's roofline fraction. */
+int cm_model_issue_flops(const cm_model *m, int32_t B, double f32[8], double b16[8]);
 
 /* ---- sampling metrics: the per-frame reductions of utils/metrics/metricsGenerator.py:70-92,
  * 120-186,293-339 (PSNR, masked PSNR, relative density error, total variation) on the device.
