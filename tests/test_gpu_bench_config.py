@@ -248,3 +248,30 @@ def test_release_keeps_training_state_across_handle_recreation():
     step = C.c_int32()
     native.check(native.lib().cm_train_opt_step(a._handle, C.byref(step), 0))
     assert step.value == 2
+
+
+def test_issue_flops_split_is_consistent_with_the_executed_flops():
+    """cm_model_issue_flops (bench.py's roofline numerator): fp32-instruction FLOPs + 16-bit-instruction FLOPs / 6 of the
+    fp32 plan == cm_model_exec_flops per class (a six-term layer issues six bf16 products per fp32-equivalent product),
+    most of the 3x3x3 work of the headline config is on the six-term form, and the f16 plan issues 1x."""
+    past, fut, t, _ = _bench_inputs()
+    net = _unet(4, 8)
+    net(fut[:8], t[:8], past[:8])
+    L, h = native.lib(), net._handle
+    ex, f32, b16 = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
+    native.check(L.cm_model_exec_flops(h, 8, ex))
+    native.check(L.cm_model_issue_flops(h, 8, f32, b16))
+    for i in range(8):
+        assert abs(f32[i] + b16[i] / 6.0 - ex[i]) <= 1e-9 * max(1.0, ex[i])
+    assert b16[0] / 6.0 > 0.8 * ex[0]          # Winograd, quarter-resolution and upsample layers
+    assert f32[0] > 0                          # stride-2 / first / last convs stay on fp32 instructions
+    i32, i16 = net.conv3_issue_flops(8)
+    assert i32 == f32[0] and i16 == b16[0]
+    net.set_precision("f16")
+    net(fut[:8], t[:8], past[:8])
+    h = net._handle                            # (a new native handle: the precision is fixed at plan-build time)
+    native.check(L.cm_model_exec_flops(h, 8, ex))
+    native.check(L.cm_model_issue_flops(h, 8, f32, b16))
+    for i in range(8):
+        assert abs(f32[i] + b16[i] - ex[i]) <= 1e-9 * max(1.0, ex[i])
+    assert b16[0] > 0.5 * ex[0]
