@@ -358,7 +358,8 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
   }
   // ---- this wave's GroupNorm group: per-channel merge of the producers' slots (lane = channel of the group) ----------
   const int c0w = wave * cw;
-  {
+  const bool norm = a.gamma != nullptr;            // false: the source enters as it is (data gradients of the training step)
+  if (norm) {
     float M = 0.f, S2 = 0.f;
     if (lane < cw) {
       const int c = c0w + lane;
@@ -376,8 +377,8 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
   }
   __syncthreads();                                // hvinfo (all waves) and the wave's own gst rows
   // every lane merges the group's channels in channel order (same chain on all lanes: no cross-lane traffic)
-  float gmean, grstd;
-  {
+  float gmean = 0.f, grstd = 1.f;
+  if (norm) {
     float N = 0.f, M = 0.f, S2 = 0.f;
     for (int i = 0; i < cw; ++i) chan_combine_q(N, M, S2, (float)V, gst[wave * 64 + i], gst[wave * 64 + 32 + i]);
     gmean = M;
@@ -396,13 +397,17 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
   const int qq = lane & ((1 << QSH) - 1);           // (64 k is a multiple of the quad count: the quad of an item does not depend on k)
   const int nsteps = B6 ? (cw + 15) >> 4 : cw >> 3;
   bool cq_ok = true;                                // B6: this lane's quad of the step lies inside the wave's channel range
-  f32x4 ld[NIT], ldg, ldb;                            // halo loads of the next step and its affine rows, in flight
+  f32x4 ld[NIT], ldg = {1.f, 1.f, 1.f, 1.f}, ldb = {0.f, 0.f, 0.f, 0.f};   // halo loads of the next step and its affine rows, in flight
+  f32x4 ldp = {1.f, 1.f, 1.f, 1.f};                   // Dropout3d multipliers of the step's channels (training forward)
   auto issue = [&](int s) {
     const int cl = (B6 ? 16 : 8) * s + 4 * qq;
     cq_ok = cl < cw;
     const int c = c0w + (cq_ok ? cl : 0);
-    ldg = *reinterpret_cast<const f32x4 *>(a.gamma + c);
-    ldb = *reinterpret_cast<const f32x4 *>(a.beta + c);
+    if (norm) {
+      ldg = *reinterpret_cast<const f32x4 *>(a.gamma + c);
+      ldb = *reinterpret_cast<const f32x4 *>(a.beta + c);
+    }
+    if (a.pm) ldp = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + c);
     const bool from0 = c < a.C0;
     const float *sp = from0 ? a.src0 + (size_t)b * V * a.C0 + c : a.src1 + (size_t)b * V * a.C1 + (c - a.C0);
     const int Cs = from0 ? a.C0 : a.C1;
@@ -417,8 +422,10 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
     for (int k = 0; k < NIT; ++k)
       if (k < nit) {
         const int it = lane + 64 * k, hv = it >> QSH;
-        f32x4 w = ld[k] * sc + sh;
+        f32x4 w = ld[k];
+        if (norm) w = w * sc + sh;
         if (a.silu) { w[0] = silu_q(w[0]); w[1] = silu_q(w[1]); w[2] = silu_q(w[2]); w[3] = silu_q(w[3]); }
+        if (a.pm) w = w * ldp;
         if (ioff[k] < 0 || !cq_ok) w = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (B6) {
           if (hv < HV) {
@@ -730,7 +737,7 @@ size_t conv_qr2_lds(const QrArgs &a, int MBP, bool b6) {
 // v2 applies when the K ranges of the 8 waves are the 8 GroupNorm groups in whole 8-channel steps
 bool conv_qr2_ok(const QrArgs &a) {
   const int Ci = a.C0 + a.C1;
-  return a.gamma && a.groups == 8 && Ci % 64 == 0 && Ci / 8 <= 32 && a.C0 % 4 == 0 && a.C1 % 4 == 0 && 2 * (a.Y + 2) * (a.X + 2) <= 192 &&
+  return (a.gamma || a.raw) && a.groups == 8 && Ci % 64 == 0 && Ci / 8 <= 32 && a.C0 % 4 == 0 && a.C1 % 4 == 0 && 2 * (a.Y + 2) * (a.X + 2) <= 192 &&
          conv_qr2_lds(a, a.Y * a.X > 32 ? 2 : 1, false) <= 160 * 1024;
 }
 

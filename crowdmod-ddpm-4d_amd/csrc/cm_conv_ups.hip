@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
   // PREC = 2 (B6): fp32 products formed on the bf16 matrix instruction from exact three-way splits x = hi + mid + lo
   // (8 + 8 + 8 mantissa bits: the split loses nothing).  Six cross terms per product -- hi*lo, lo*hi, mid*mid, hi*mid, mid*hi,
   // hi*hi; the three dropped ones are <= 2^-24 of the product -- accumulate in fp32: the error against an fp64 reference is
-  // that of the fp32 instruction (simulation in DESIGN section 6: rms 2.7e-7 vs 3.3e-7 of the k-ordered fp32 chain at K = 512),
+  // fp32-level (tools/sim_six_term.py, K = 512, one rounding per product as the worst case: rms 7.9e-7 of the result's rms against
+  // 4.1e-7 of the k-ordered fp32 chain, three terms 4.4e-6; measured: whole-forward error against the reference 2.1e-6, exact-fp32 path 2.3e-6),
   // and 16 channels take 6 x 32 cycles instead of 8 x 64.  The staged box is split once per voxel at the LDS write (three
   // bf16 planes per row), the weights arrive pre-split (pack_ups_b6).
   constexpr bool F16 = PREC == 1, B6 = PREC == 2;

@@ -167,6 +167,9 @@ struct QrArgs {
   int s2C0, s2C1;
   const float *s2w;              // [Co / 32][Cs / 8][64 lanes][4]
   int qshift;                    // (set by the launcher) log2 of the staging's channel-quad lane count
+  const float *pm;               // optional per-(sample, input channel) multiplier after the activation: Dropout3d of the training forward (conv_qr2 only)
+  int pm_stride;
+  int raw;                       // 1 with gamma == null: no normalisation at all, conv_qr2 still applies (data gradients)
 };
 bool conv_qr_ok(const QrArgs &a);
 bool conv_qr2_b6_ok(const QrArgs &a);

@@ -123,6 +123,7 @@ struct Op {
   bool qr = false;          // whole-sample kernel of the lowest resolution (cm_conv_qr.hip), inference plan
   float *d_wqr = nullptr, *d_wqr_skip = nullptr;
   float *d_wqr_b6 = nullptr;    // exact bf16 x 3 split of d_wqr for the six-term form of conv_qr2 (pack_qr_b6)
+  bool train_qr = false;        // the training forward may take conv_qr2 as well (set by train_setup once the geometry is checked)
   long long wqr_floats = 0;
   bool qr_consumer = false; // OP_GNFIN whose only consumer is a qr conv: that kernel finalises the statistics itself
   bool first_k = false;     // the UNet's first conv on its dedicated kernel (cm_conv_io.hip)
@@ -1338,7 +1339,12 @@ int run_conv_qr(cm_model *m, Op &op, int B, hipStream_t st, int b0) {
   q.wq6 = op.d_wqr_b6;
   q.temb = ca.temb; q.temb_stride = ca.temb_stride; q.tidx = ca.tidx + b0;
   q.resid = ca.resid ? ca.resid + (size_t)b0 * V * ca.res_cs : nullptr; q.res_cs = ca.res_cs;
-  if (op.d_wqr_skip) {
+  if (m->train_fwd) {
+    // training forward (six-term form only, see run_conv): Dropout3d multipliers on the activated input, the time-embedding rows
+    // of this batch, the block's skip conv as its own op (its output arrives as the residual)
+    if (op.pm_off >= 0) { q.pm = m->dropmask + (size_t)b0 * m->nproj + op.pm_off; q.pm_stride = m->nproj; }
+    if (m->use_train_temb && op.temb_off >= 0) { q.temb = m->train_temb + op.temb_off; q.tidx = m->train_iota + b0; }
+  } else if (op.d_wqr_skip) {
     q.s2w = op.d_wqr_skip;
     q.s2src0 = op.skip0->d + (size_t)b0 * V * op.skip0->C; q.s2C0 = op.skip0->C;
     q.s2src1 = op.skip1 ? op.skip1->d + (size_t)b0 * V * op.skip1->C : nullptr; q.s2C1 = op.skip1 ? op.skip1->C : 0;
@@ -1352,13 +1358,17 @@ int run_conv_qr(cm_model *m, Op &op, int B, hipStream_t st, int b0) {
   q.stat_cnt = op.stat_act->cnt + (size_t)b0 * ns;
   op.stat_act->nslots = ns;
   op.prof_B = B;
+  if (m->train_fwd && !cm::conv_qr2_b6_ok(q)) return fail("quarter-resolution conv %s: no six-term form for the training forward", op.label.c_str());
   CM_HIP(cm::launch_conv_qr(q, st));
   return 0;
 }
 
 int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   if (op.skip_if_fused && !m->train_fwd) return 0;  // absorbed by the block's conv_2 (inference plan)
-  if (op.qr && !m->train_fwd) return run_conv_qr(m, op, B, st, b0);
+  // (training forward: the same whole-sample kernel in its six-term form -- it finalises the GroupNorm of its input from the
+  //  producers' partials like the inference plan does; the gn_finalize op still runs there for the backward's mean / rstd rows)
+  static const bool no_train_qr = cm::diag_env("CM_NO_TRAIN_QR") != nullptr;
+  if (op.qr && (!m->train_fwd || (op.d_wqr_b6 && op.train_qr && !no_train_qr))) return run_conv_qr(m, op, B, st, b0);
   if (op.tuned_B < 0 && op.wino) {
     // feasibility is known only with the launch geometry: a grid the Winograd tiles do not fit falls back to the
     // direct kernel (its fragments `wfrag` are packed for every conv; NB = 1 was fixed before packing)
