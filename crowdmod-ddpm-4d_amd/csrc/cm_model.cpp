@@ -2521,7 +2521,7 @@ static int exec_flops_split(const cm_model *m, int32_t B, double flops[8], doubl
       f = tiles * 128.0 * op.f16d_mbw * a.Co * (Ci * 27.0 + (op.d_w16d_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
       mult16 = 1.0;
     } else if (op.qr) {
-      if (op.d_wqr_b6 && a.Yo * a.Xo <= 32) mult16 = 6.0;
+      if (op.d_wqr_b6 && 8 * (a.Yo + 2) * (a.Xo + 2) <= 64 * 9) mult16 = 6.0;   // (conv_qr2_b6_ok)
       const double rows = 2.0 * (a.Yo * a.Xo > 32 ? 2 : 1) * 32;        // whole 32-row blocks, one or two per plane
       f = rows * a.Co * (Ci * 18.0 + (op.d_wqr_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
     } else if (op.wino) {
