@@ -429,13 +429,10 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
         if (ioff[k] < 0 || !cq_ok) w = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (B6) {
           if (hv < HV) {
-            f32x4 rem = w;
+            cm_u32x2_t t3[3];
+            cm_split3_bf16(w, t3);                  // hi / mid / lo planes, exact remainders
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm) {
-              const bf16x4q hb = {(__bf16)rem[0], (__bf16)rem[1], (__bf16)rem[2], (__bf16)rem[3]};
-              *reinterpret_cast<bf16x4q *>(dst + (size_t)hv * SS + 8 * tm) = hb;
-              if (tm < 2) rem = rem - f32x4{(float)hb[0], (float)hb[1], (float)hb[2], (float)hb[3]};   // exact remainder
-            }
+            for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<cm_u32x2_t *>(dst + (size_t)hv * SS + 8 * tm) = t3[tm];
           }
         } else {
           if (hv < HV) *reinterpret_cast<f32x4 *>(dst + (size_t)hv * SS) = w;

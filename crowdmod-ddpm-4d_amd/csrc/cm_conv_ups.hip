@@ -151,16 +151,11 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
           const int h = (tid >> 3) + 32 * k;
           const f32x4 w = ((hok >> k) & 1u) ? ld[kk] : f32x4{0.f, 0.f, 0.f, 0.f};
           if constexpr (B6) {
-            bf16x4 t3[3];
-            f32x4 rem = w;
-#pragma unroll
-            for (int tm = 0; tm < 3; ++tm) {
-              t3[tm] = bf16x4{(__bf16)rem[0], (__bf16)rem[1], (__bf16)rem[2], (__bf16)rem[3]};
-              if (tm < 2) rem = rem - f32x4{(float)t3[tm][0], (float)t3[tm][1], (float)t3[tm][2], (float)t3[tm][3]};   // exact
-            }
+            cm_u32x2_t t3[3];
+            cm_split3_bf16(w, t3);                  // hi / mid / lo planes, exact remainders
             if (h < HV) {
 #pragma unroll
-              for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<bf16x4 *>(A + (size_t)h * S + 16 * tm + 2 * q) = t3[tm];
+              for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<cm_u32x2_t *>(A + (size_t)h * S + 16 * tm + 2 * q) = t3[tm];
             }
           } else if constexpr (F16) {
             const f16x4 hv = {(_Float16)w[0], (_Float16)w[1], (_Float16)w[2], (_Float16)w[3]};

@@ -735,13 +735,10 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
           for (int j = 0; j < 4; ++j) d[i * 4 + j] = *reinterpret_cast<const f32x4 *>(R + rbase + (i * RXH + j) * RS_);
         auto put = [&](int k, const f32x4 v) {     // component k = xi_y * 4 + xi_x of this item
           if constexpr (B6) {
-            f32x4 rem = v;
+            cm_u32x2_t t3[3];
+            cm_split3_bf16(v, t3);                  // hi / mid / lo planes, exact remainders
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm) {
-              const bf16x4 hb = {(__bf16)rem[0], (__bf16)rem[1], (__bf16)rem[2], (__bf16)rem[3]};
-              *reinterpret_cast<bf16x4 *>(uw + (size_t)k * URC * S + 8 * tm) = hb;
-              if (tm < 2) rem = rem - f32x4{(float)hb[0], (float)hb[1], (float)hb[2], (float)hb[3]};   // exact remainder
-            }
+            for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<cm_u32x2_t *>(uw + (size_t)k * URC * S + 8 * tm) = t3[tm];
           } else if constexpr (F16) {
             const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             *reinterpret_cast<f16x4 *>(uw + (size_t)k * URC * S) = hv;
