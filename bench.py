@@ -173,7 +173,8 @@ def run_train(a):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "samples_per_s": B / dt_s,
         "config": {"workload": "config/ATC.yml training step (BASELINE configs[2]), batch %d, fp32 (the reference trains under "
                                "fp16 autocast: this is the wider type)" % B, "channels": Cc, "grid": [H, W]},
-        "roofline": {"kernel": "whole training step (forward + data-gradient + weight-gradient convolutions on v_mfma_f32_32x32x2_f32)",
+        "roofline": {"kernel": "whole training step (forward + data-gradient convolutions: six-term bf16 products in the Winograd / "
+                               "quarter-resolution / upsample layers; weight-gradient convolutions on v_mfma_f32_32x32x2_f32)",
                      "bound": "mfma", "achieved": exe, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": exe / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                      "algorithmic_tflops": ach, "algorithmic_frac": ach / FP32_MFMA_PEAK_TFLOPS,
@@ -182,7 +183,10 @@ def run_train(a):
                              "data gradient + weight gradient); `achieved` / `frac` count 3 x the matrix-core FLOPs the forward "
                              "ISSUES in its reduced forms (Winograd 16/36, two-plane grids 18/27, parity-form upsample 8/27 -- the "
                              "data- and weight-gradient kernels run the same forms), i.e. the hardware fraction; `algorithmic_frac` "
-                             "can exceed it by the algorithmic saving and is not a roof"},
+                             "can exceed it by the algorithmic saving and is not a roof.  Priced against the fp32 instruction's peak "
+                             "although ~70 % of the forward / data-gradient FLOPs are issued as six bf16 products each (2.7x the fp32 "
+                             "rate): a mixed-instruction roof like the sampling line's needs per-kernel FLOP counts of the backward, "
+                             "which the library does not export"},
         "loss_first": losses[0], "loss_last": losses[-1]}))
 
 
