@@ -263,3 +263,32 @@ def test_stage_once_upsample_kernel_agrees_with_the_generic_parity_kernel(tmp_pa
         assert np.isfinite(a).all() and a.shape == b.shape
         assert not np.array_equal(a, b), "the switch did not change the kernel"
         assert float(np.abs(a - b).max()) <= 2e-5 * max(1.0, float(np.abs(b).max())), gname
+
+
+def test_six_term_bf16_products_agree_with_the_fp32_matrix_instructions(tmp_path):
+    """The fp32 plan forms the products of its Winograd, quarter-resolution and upsample layers from exact three-way bf16 splits
+    (six v_mfma_f32_32x32x16_bf16 terms, fp32 accumulate).  Against the same kernels on the fp32 matrix
+    instruction (child process with CM_DIAG=1 and the CM_NO_*_B6 switches, read once per process): whole-denoiser forwards at
+    B = 8 on all three reference grids agree to fp32 rounding -- the three dropped cross terms are <= 2^-24 of a product --
+    and are not bit-identical (the switches took effect).  Both sit within 1e-4 of the reference on the fixture samples
+    (test_gpu_parity.py, test_gpu_bench_config.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    res = {}
+    off = {"CM_DIAG": "1", "CM_NO_WINO_B6": "1", "CM_NO_QR_B6": "1", "CM_NO_UPS_B6": "1"}
+    for tag, extra in (("six", {}), ("fp32", off)):
+        path = str(tmp_path / f"{tag}.npz")
+        env = dict(os.environ, **extra)
+        env.pop("CM_CONV_DBG", None)
+        r = subprocess.run([sys.executable, "-c", _UPS_CHILD.format(root=root, tests=here, path=path)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(path)
+    for gname in ("atc", "cr120", "atc2x"):
+        a, b = res["six"][gname], res["fp32"][gname]
+        assert np.isfinite(a).all() and a.shape == b.shape
+        assert not np.array_equal(a, b), "the switches did not change the kernels"
+        assert float(np.abs(a - b).max()) <= 1e-5 * max(1.0, float(np.abs(b).max())), gname
