@@ -252,6 +252,8 @@ hipError_t launch_time_mlp(const float *table, const float *W1, const float *b1,
                            float *out, const long long *rowidx, hipStream_t st);
 // softmax(q k^T / sqrt(d)) v per (sample, head); qkv channels-last [B][S][3E]
 hipError_t launch_attn_core(const float *qkv, float *out, int B, int S, int E, int heads, hipStream_t st);
+// the same on f16 matrix-core operands (fp32 accumulate, fp32 softmax): reduced-precision plan, head dimension 32
+hipError_t launch_attn_core_f16(const float *qkv, float *out, int B, int S, int E, int heads, hipStream_t st);
 
 // Fused AttentionBlock (cm_attn_block.hip): GroupNorm + in-projection + softmax(q k^T) v + partial out-projection
 // per (head, sample); the heads are summed by launch_ksplit_combine (S = heads, stride = B * S * E).

@@ -736,6 +736,131 @@ hipError_t launch_attn_core(const float *qkv, float *out, int B, int S, int E, i
 }
 
 // --------------------------------------------------------------------------------
+// Attention core of the reduced-precision plan (cm_model_set_precision(F16); the reference's torch.amp.autocast covers
+// nn.MultiheadAttention, ddpm.py:116-120 / layers.py:16) for token counts beyond the fused block's LDS design (216 tokens on
+// the 24x72 grid): softmax(q k^T / sqrt(d)) v per (head, sample) on v_mfma_f32_32x32x16_f16 -- f16 operands, fp32
+// accumulation, fp32 softmax.  One 256-thread workgroup per (head, sample): K and V^T live in LDS as f16, each wave takes
+// query blocks of 32 rows.  Scores are computed TRANSPOSED (S^T = K Q^T: keys in the rows, queries in the columns), so in the
+// accumulator layout a lane owns ONE query and its registers are keys: the online softmax is lane-local plus one xor-32
+// exchange for the running maximum, and the probabilities are already the B operand of O^T += V^T P^T -- registers
+// 8u .. 8u + 7 of a lane are the keys 16u + {0..3, 8..11} + 4 hh of the block, the order V^T's fragments are read in.
+// d = 32 only (the reference's 4 heads of 128 channels); the fp32 plan keeps attn_core_kernel.
+// --------------------------------------------------------------------------------
+typedef _Float16 f16x8m __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4m __attribute__((ext_vector_type(4)));
+typedef float f32x16m __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void attn_core_f16_kernel(const float *__restrict__ qkv, float *__restrict__ out, int S, int E) {
+  constexpr int D = 32, KS = D + 8;                 // K row stride in halves (80 B: 16-byte aligned, conflict-free b128 reads)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  const int nkb = (S + 31) >> 5, Sp = nkb * 32, VS = Sp + 8;   // V^T row stride in halves (8-byte aligned)
+  _Float16 *Ks = reinterpret_cast<_Float16 *>(smraw);           // [Sp][KS]
+  _Float16 *Vt = Ks + (size_t)Sp * KS;                          // [D][VS]
+  const int hd = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const float *base = qkv + (size_t)b * S * 3 * E;
+  // ---- stage K (rows) and V (transposed) as f16; rows / columns beyond S are zero ----
+  for (int i = tid; i < Sp * (D / 4); i += 256) {
+    const int s = i / (D / 4), d4 = i % (D / 4);
+    f32x4 k = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
+    if (s < S) {
+      k = *reinterpret_cast<const f32x4 *>(base + (size_t)s * 3 * E + E + hd * D + 4 * d4);
+      v = *reinterpret_cast<const f32x4 *>(base + (size_t)s * 3 * E + 2 * E + hd * D + 4 * d4);
+    }
+    *reinterpret_cast<f16x4m *>(Ks + (size_t)s * KS + 4 * d4) = f16x4m{(_Float16)k[0], (_Float16)k[1], (_Float16)k[2], (_Float16)k[3]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Vt[(size_t)(4 * d4 + e) * VS + s] = (_Float16)v[e];
+  }
+  __syncthreads();
+  const float scale = rsqrtf((float)D);
+  for (int qb = wave; qb < nkb; qb += 4) {
+    const int q = qb * 32 + r, qc = q < S ? q : S - 1;
+    // B operand: Q^T, lane (query r, hh): dims 16 g + 8 hh .. + 7, scaled as the fp32 kernel scales q
+    f16x8m qf[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float *qp = base + (size_t)qc * 3 * E + hd * D + 16 * g + 8 * hh;
+      const f32x4 q0 = *reinterpret_cast<const f32x4 *>(qp) * scale, q1 = *reinterpret_cast<const f32x4 *>(qp + 4) * scale;
+      qf[g] = f16x8m{(_Float16)q0[0], (_Float16)q0[1], (_Float16)q0[2], (_Float16)q0[3],
+                     (_Float16)q1[0], (_Float16)q1[1], (_Float16)q1[2], (_Float16)q1[3]};
+    }
+    f32x16m o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+    float mx = -3.0e38f, l = 0.f;                   // running maximum (shared by the two halves of a query) and this half's sum
+    for (int kb = 0; kb < nkb; ++kb) {
+      // S^T block: keys 32 kb + (row), A = K rows of this lane's key
+      f32x16m sc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const f16x8m kf = *reinterpret_cast<const f16x8m *>(Ks + (size_t)(kb * 32 + r) * KS + 16 * g + 8 * hh);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[g], sc, 0, 0, 0);
+      }
+      // this lane's 16 keys of the block: key = 32 kb + (reg & 3) + 8 (reg >> 2) + 4 hh
+      float bm = -3.0e38f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int key = kb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        if (key >= S) sc[reg] = -3.0e38f;
+        bm = fmaxf(bm, sc[reg]);
+      }
+      bm = fmaxf(bm, __shfl_xor(bm, 32));
+      const float mnew = fmaxf(mx, bm);
+      const float corr = __expf(mx - mnew);
+      mx = mnew;
+      l *= corr;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[i] *= corr;
+      float ps = 0.f;
+      f16x8m pf[2];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int key = kb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        const float pv = key < S ? __expf(sc[reg] - mnew) : 0.f;
+        ps += pv;
+        pf[reg >> 3][reg & 7] = (_Float16)pv;
+      }
+      l += ps;
+      // O^T (dims x queries) += V^T P^T over the block's 32 keys: two K = 16 groups in the register order above
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const _Float16 *vp = Vt + (size_t)r * VS + kb * 32 + 16 * u + 4 * hh;      // lane (dim r, hh): keys 16u + 4hh + {0..3, 8..11}
+        const f16x4m v0 = *reinterpret_cast<const f16x4m *>(vp), v1 = *reinterpret_cast<const f16x4m *>(vp + 8);
+        const f16x8m vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u], o, 0, 0, 0);
+      }
+    }
+    l += __shfl_xor(l, 32);
+    if (q < S) {
+      const float inv = 1.0f / l;
+      float *op = out + ((size_t)b * S + q) * E + hd * D;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) op[(reg & 3) + 8 * (reg >> 2) + 4 * hh] = o[reg] * inv;
+    }
+  }
+}
+
+hipError_t launch_attn_core_f16(const float *qkv, float *out, int B, int S, int E, int heads, hipStream_t st) {
+  if (heads <= 0 || E / heads != 32 || E % heads || S < 1) return hipErrorInvalidValue;
+  const int Sp = (S + 31) / 32 * 32;
+  const size_t smem = ((size_t)Sp * (32 + 8) + (size_t)32 * (Sp + 8)) * sizeof(_Float16);
+  if (smem > 160 * 1024) return hipErrorInvalidValue;
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_set[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_core_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set[dev & 63] = true;
+  }
+  hipLaunchKernelGGL(attn_core_f16_kernel, dim3(heads, B), dim3(256), smem, st, qkv, out, S, E);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------
 // Device RNG: Philox4x32-10 keyed by the seed, counter = (element quad, global
 // sample id, step, stream).  Independent of batch sharding: sample i of the job
 // draws the same numbers on 1 GPU and on 8.

@@ -1595,8 +1595,14 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
         break;
       }
       case OP_ATTN:
-        CM_HIP(cm::launch_attn_core(op.qkv + (size_t)b0 * op.S * 3 * op.E, op.aout + (size_t)b0 * op.S * op.E, B, op.S,
-                                    op.E, ATTN_HEADS, st));
+        // reduced-precision plan, inference: QK^T and PV on f16 matrix-core operands (the fp32 plan and every training
+        // forward keep the exact fp32 kernel)
+        if (m->precision == CM_PRECISION_F16 && !m->train_fwd && op.E / ATTN_HEADS == 32 && !cm::diag_env("CM_NO_ATTN_F16"))
+          CM_HIP(cm::launch_attn_core_f16(op.qkv + (size_t)b0 * op.S * 3 * op.E, op.aout + (size_t)b0 * op.S * op.E, B, op.S,
+                                          op.E, ATTN_HEADS, st));
+        else
+          CM_HIP(cm::launch_attn_core(op.qkv + (size_t)b0 * op.S * 3 * op.E, op.aout + (size_t)b0 * op.S * op.E, B, op.S,
+                                      op.E, ATTN_HEADS, st));
         break;
       case OP_ATTNBLK: {
         const Op &gop = m->ops[op.ab_gn], &qop = m->ops[op.ab_qkv], &oop = m->ops[op.ab_outc];

@@ -76,3 +76,24 @@ def test_f16_loop_on_doubled_grid_and_precision_rules():
         native.check(L.cm_model_set_precision(m.denoiser._handle, 0))
     with pytest.raises(ValueError):
         m.denoiser.set_precision("bf16")
+
+
+def test_f16_attention_core_on_matrix_cores_agrees_with_the_fp32_core():
+    """216 tokens (24x72 grid) run the generic attention chain; under the reduced-precision plan its core -- QK^T, softmax,
+    PV -- takes f16 matrix-core operands with fp32 accumulation and an fp32 softmax (attn_core_f16_kernel; the reference's
+    autocast covers nn.MultiheadAttention, ddpm.py:116-120 / layers.py:16).  Against the fp32 plan's exact core on the same
+    inputs: the first attention block's core output within 2e-2 of its own scale (both plans feed it slightly different
+    q, k, v: the layers before it already differ by the f16 convolutions), finite, and not identical."""
+    H, W = FULL_GRIDS["atc2x"]
+    C_ = 3
+    g = load("fwd.npz")
+    past, fut = synth_inputs(2, C_, H, W, 5, 3, f"full/atc2x/c{C_}")
+    n32, n16 = _unet(C_), _unet(C_, precision="f16")
+    n32(fut, g["atc2x_c3/t"], past)
+    n16(fut, g["atc2x_c3/t"], past)
+    name = "encoder_blocks.4.attention.core"
+    a32, a16 = n32.debug_activation(name)[:2], n16.debug_activation(name)[:2]
+    assert a32.shape == a16.shape and np.isfinite(a16).all()
+    scale = float(np.abs(a32).max())
+    err = float(np.abs(a16 - a32).max())
+    assert 0.0 < err <= 2e-2 * max(1.0, scale), (err, scale)
