@@ -819,6 +819,112 @@ __global__ __launch_bounds__(256) void conv1x1_flat_kernel(const ConvArgs a, lon
   }
 }
 
+// The same flat-row GEMM on f16 matrix-core operands (reduced-precision plan, BASELINE configs[4] "fp16 with MFMA 1x1 convs"; the
+// reference's autocast covers the attention projections, ddpm.py:116-120 / layers.py:14): a wave owns 32 rows and NB 32-channel
+// output blocks, a step is 16 input channels -- lane (row r, half h) loads channels 16 g + 8 h .. + 7 (two 16-byte loads), applies
+// the GroupNorm affine / SiLU / dropout multiplier in fp32, rounds to f16, and issues ONE v_mfma_f32_32x32x16_f16 per output block
+// against the packed f16 fragments (pack_1x1_f16: [n tile][16-channel group][block][lane][8 halves]); fp32 accumulation, bias and
+// residual in fp32.  No statistics (conv1x1_f16_ok): the attention in-projection and unfused skip convs.  (A variant whose
+// 32-row blocks were cut per sample and wrote statistics slots -- the out-projection -- measured 1 % SLOWER per step than the
+// generic fp32 kernel on the 24x72 grid and is not kept: that launch is a latency chain, not matrix work.)
+typedef _Float16 f16x8c __attribute__((ext_vector_type(8)));
+template <int NB>
+__global__ __launch_bounds__(256) void conv1x1_f16_kernel(const ConvArgs a, long long N, int V) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const long long row0 = ((long long)blockIdx.x * 4 + wave) * 32;
+  if (row0 >= N) return;                          // (wave-uniform; no barriers in this kernel)
+  const int nt = blockIdx.y;
+  const long long n = row0 + r, nn = n < N ? n : N - 1;
+  const int b = (int)(nn / V);
+  const int Ctot = a.C0 + a.C1;
+  const int g0n = a.C0 >> 4, ngr = g0n + (a.C1 >> 4);
+  const f32x4 *wt = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * ngr * NB * 64 + lane;
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+  // four 16-channel groups per round: all their loads (rows, affine rows, weight fragments) are issued before the first use --
+  // one memory round trip per 64 channels (a load -> use loop pays one per group: 8 dependent round trips for 128 channels)
+  constexpr int GB = 4;
+  for (int g0 = 0; g0 < ngr; g0 += GB) {
+    f32x4 a0[GB], a1[GB], s0[GB], s1[GB], h0[GB], h1[GB], p0[GB], p1[GB], wv[GB][NB];
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      const int g = g0 + u < ngr ? g0 + u : ngr - 1;
+      const float *src;
+      int Cs, c0, cg0;
+      if (g < g0n) { src = a.src0; Cs = a.C0; c0 = g * 16; cg0 = c0; }
+      else { src = a.src1; Cs = a.C1; c0 = (g - g0n) * 16; cg0 = a.C0 + c0; }
+      const float *ap = src + (size_t)nn * Cs + c0 + 8 * h;
+      a0[u] = *reinterpret_cast<const f32x4 *>(ap);
+      a1[u] = *reinterpret_cast<const f32x4 *>(ap + 4);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) wv[u][nb] = wt[((size_t)g * NB + nb) * 64];
+      if (a.gn) {
+        const float *gp = a.gn + (size_t)b * 2 * Ctot + cg0 + 8 * h;
+        s0[u] = *reinterpret_cast<const f32x4 *>(gp); s1[u] = *reinterpret_cast<const f32x4 *>(gp + 4);
+        h0[u] = *reinterpret_cast<const f32x4 *>(gp + Ctot); h1[u] = *reinterpret_cast<const f32x4 *>(gp + Ctot + 4);
+      }
+      if (a.pm) {
+        const float *pmp = a.pm + (size_t)b * a.pm_stride + cg0 + 8 * h;
+        p0[u] = *reinterpret_cast<const f32x4 *>(pmp); p1[u] = *reinterpret_cast<const f32x4 *>(pmp + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      if (g0 + u >= ngr) break;
+      f32x4 x0 = a0[u], x1 = a1[u];
+      if (a.gn) {
+        x0 = x0 * s0[u] + h0[u];
+        x1 = x1 * s1[u] + h1[u];
+        if (a.silu) {
+          x0[0] = silu_f(x0[0]); x0[1] = silu_f(x0[1]); x0[2] = silu_f(x0[2]); x0[3] = silu_f(x0[3]);
+          x1[0] = silu_f(x1[0]); x1[1] = silu_f(x1[1]); x1[2] = silu_f(x1[2]); x1[3] = silu_f(x1[3]);
+        }
+      }
+      if (a.pm) { x0 = x0 * p0[u]; x1 = x1 * p1[u]; }
+      const f16x8c af = {(_Float16)x0[0], (_Float16)x0[1], (_Float16)x0[2], (_Float16)x0[3],
+                         (_Float16)x1[0], (_Float16)x1[1], (_Float16)x1[2], (_Float16)x1[3]};
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(f16x8c, wv[u][nb]), acc[nb], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int co = (nt * NB + nb) * 32 + r;
+    if (co >= a.Co) continue;
+    const float bias = a.bias[co];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const long long orow = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (orow < N) {
+        float v = acc[nb][reg] + bias;
+        if (a.resid) v += a.resid[(size_t)orow * a.res_cs + co];
+        a.out[(size_t)orow * a.out_cs + co] = v;
+      }
+    }
+  }
+}
+
+bool conv1x1_f16_ok(const ConvArgs &a, int NB) {
+  return a.ntaps == 1 && a.td == 1 && a.stride == 1 && !a.par && !a.ups && !(a.C0 & 15) && !(a.C1 & 15) && !a.stat_part && a.ks <= 1 &&
+         !a.temb && !a.s2w && (NB == 1 || NB == 2) && a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo;
+}
+
+hipError_t launch_conv1x1_f16(const ConvArgs &a, int NB, hipStream_t st) {
+  if (!conv1x1_f16_ok(a, NB)) return hipErrorInvalidValue;
+  const int V = a.Zo * a.Yo * a.Xo;
+  const long long N = (long long)a.B * V;
+  const dim3 grid((unsigned)((N + 127) / 128), (unsigned)((a.Co + 32 * NB - 1) / (32 * NB)));
+  if (NB == 1) hipLaunchKernelGGL(conv1x1_f16_kernel<1>, grid, dim3(256), 0, st, a, N, V);
+  else hipLaunchKernelGGL(conv1x1_f16_kernel<2>, grid, dim3(256), 0, st, a, N, V);
+  return hipGetLastError();
+}
+
 bool conv1x1_flat_ok(const ConvArgs &a, int NB) {
   return a.ntaps == 1 && a.td == 1 && a.stride == 1 && !a.par && !a.ups && a.CK == 32 && !(a.C0 & 31) && !(a.C1 & 31) && !a.stat_part &&
          a.ks <= 1 && !a.temb && !a.s2w && !a.f16 && (NB == 1 || NB == 2) && a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo &&

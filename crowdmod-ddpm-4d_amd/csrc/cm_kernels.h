@@ -120,6 +120,10 @@ void conv_build_tables(const ConvArgs &a, int MB, int *hvtab /*[conv_halo_voxels
 int conv_halo_voxels(const ConvArgs &a);
 // MB x NB = number of 32x32 accumulator blocks per wave (workgroup tile 32MB x 32NB).
 hipError_t launch_conv(const ConvArgs &a, int MB, int NB, hipStream_t st);
+// 1x1x1 stride-1 conv without output statistics as a flat-row GEMM on f16 matrix-core operands (reduced-precision plan);
+// a.wfrag = pack_1x1_f16 fragments [n tile][16-channel group][block][lane][8 halves]
+bool conv1x1_f16_ok(const ConvArgs &a, int NB);
+hipError_t launch_conv1x1_f16(const ConvArgs &a, int NB, hipStream_t st);
 bool conv_variant_exists(int MB, int NB);
 // Upsample conv, parity form with the source tile staged once for four parity classes (cm_conv_ups.hip); a.bz / by / bx =
 // the SOURCE tile of conv_ups_pick, nbp = the NB the weights were packed with

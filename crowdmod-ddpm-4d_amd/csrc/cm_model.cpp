@@ -110,6 +110,7 @@ struct Op {
   float *d_wwino_b6 = nullptr;  // fp32 plan, inference forward, two-tile layers: exact bf16 x 3 split of d_wwino (pack_wino_b6)
   long long wwino_floats = 0;   // element count of d_wwino
   float *d_wfrag16 = nullptr;   // f16 fragments of a parity-form upsample conv (reduced-precision plan)
+  float *d_w1x1_16 = nullptr;   // f16 fragments of a 1x1x1 conv without statistics (pack_1x1_f16; reduced-precision plan, inference)
   long long wpar_stride16 = 0;
   bool f16d = false;        // reduced-precision plan: direct f16-operand kernel (cm_conv_f16.hip) instead of the Winograd one
   int f16d_bz = 0, f16d_by = 0, f16d_bx = 0, f16d_mbw = 0;
@@ -622,6 +623,25 @@ std::vector<float> pack_wino_b6(const std::vector<float> &ww) {
   return packed;
 }
 
+// f16 fragments of a 1x1x1 conv for conv1x1_f16_kernel: [n tile][16-channel group][block][lane 64][8 halves],
+// lane (r, h) of block nb holds W[co = (nt NB + nb) 32 + r][ci = 16 g + 8 h + j]; W is [Co][Ci]
+std::vector<float> pack_1x1_f16(const float *W, int Co, int Ci, int NB) {
+  const int TN = 32 * NB, ntn = (Co + TN - 1) / TN, ng = Ci / 16;
+  std::vector<uint16_t> out((size_t)ntn * ng * NB * 64 * 8, 0);
+  size_t o = 0;
+  for (int nt = 0; nt < ntn; ++nt)
+    for (int g = 0; g < ng; ++g)
+      for (int nb = 0; nb < NB; ++nb)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j, ++o) {
+            const int co = (nt * NB + nb) * 32 + (lane & 31), ci = 16 * g + 8 * (lane >> 5) + j;
+            if (co < Co) out[o] = f32_to_f16_bits(W[(size_t)co * Ci + ci]);
+          }
+  std::vector<float> packed(out.size() / 2);
+  std::memcpy(packed.data(), out.data(), out.size() * 2);
+  return packed;
+}
+
 int pick_ck(int C0, int C1) {
   for (int ck : {32, 16, 8})
     if (C0 % ck == 0 && C1 % ck == 0) return ck;
@@ -909,6 +929,11 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     }
   } else {
     wf = pack_conv_weights(wi.data(), (int)w.shape[0], Ci_ref, s.ntaps, Ci_pad, a.CK, op.NB);
+    // reduced-precision plan: 1x1x1 convs without output statistics (attention in-projection, unfused skip convs) on f16 operands
+    if (m->precision == CM_PRECISION_F16 && s.ntaps == 1 && s.stride == 1 && !s.ups && !s.stats && !s.temb && Ci_ref == Ci_pad &&
+        a.C0 % 16 == 0 && a.C1 % 16 == 0 && !cm::diag_env("CM_NO_1X1_F16") &&
+        upload(m, pack_1x1_f16(wi.data(), (int)w.shape[0], Ci_ref, op.NB), &op.d_w1x1_16))
+      return 1;
   }
   // upsample convs: the source tile staged once for four parity classes (cm_conv_ups.hip) when a tile fits
   if (parity && a.CK == 32 && !s.s1 && !s.gn && !s.temb && !s.resid && s.Co % 32 == 0 && s.Co == s.out->C && !cm::diag_env("CM_NO_UPS") &&
@@ -1513,6 +1538,11 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   } else if (op.small_n) {
     CM_HIP(cm::launch_conv_smalln(ca, op.MB, op.d_wsmall, st));
   } else {
+    if (op.d_w1x1_16 && !m->train_fwd && cm::conv1x1_f16_ok(ca, op.NB)) {
+      ca.wfrag = op.d_w1x1_16;
+      CM_HIP(cm::launch_conv1x1_f16(ca, op.NB, st));
+      return 0;
+    }
     if (op.d_wfrag16 && !m->train_fwd && cm::conv_par_f16_variant(op.MB, op.NB, ca.bz, ca.by, ca.bx)) {
       ca.wfrag = op.d_wfrag16; ca.wpar_stride = op.wpar_stride16; ca.f16 = 1;   // f16 operands, fp32 accumulate
     }
