@@ -48,8 +48,9 @@ class UNet:
         self.precision = "f32"
 
     def set_precision(self, precision: str):
-        """'f32' (default, exact) or 'f16': f16 matrix-core operands with fp32 accumulation in the Winograd 3x3x3
-        layers of the inference plan -- the counterpart of the reference's torch.amp.autocast (ddpm.py:116-120)."""
+        """'f32' (default: fp32 arithmetic) or 'f16': f16 matrix-core operands with fp32 accumulation in the stride-1
+        3x3x3 layers, the upsample convs and -- on grids whose attention runs the generic chain -- the attention core and
+        in-projection of the inference plan: the counterpart of the reference's torch.amp.autocast (ddpm.py:116-120)."""
         if precision not in ("f32", "f16"):
             raise ValueError(f"precision {precision!r}: 'f32' or 'f16'")
         if precision != self.precision:
