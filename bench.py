@@ -129,9 +129,156 @@ def cpu_baseline(res, channels: int, batch: int, budget_s: float):
                       + ", ".join(f"{c}: {1.0 / probe[c]:.2f}/s" for c in cands) + f"; host has {ncpu} logical CPUs"}
 
 
-def run_train(a):
+def profile_roofline(model, run, steps, nb, lanes):
+    """Roofline of the dominant kernel class (all 3x3x3 conv launches): a profiled re-run of the same K steps with HIP
+    events around every launch on its launch stream, as ONE batch lane."""
+    import torch
+    from crowdmod_ddpm_4d_amd import native
+    L = native.lib()
+    h = model.denoiser._handle
+    native.check(L.cm_profile_enable(h, 1))
+    run(steps)
+    torch.cuda.synchronize()
+    ms = (C.c_float * 8)()
+    cnt = (C.c_int64 * 8)()
+    native.check(L.cm_profile_read(h, ms, cnt))
+    un = (C.c_float * 8)()
+    native.check(L.cm_profile_read_union(h, un))     # per class: union of its launch intervals over the batch lanes
+    if os.environ.get("CM_BENCH_REPORT"):
+        buf = C.create_string_buffer(1 << 16)
+        native.check(L.cm_profile_report(h, buf, len(buf)))
+        with open(os.environ["CM_BENCH_REPORT"], "w") as fo:
+            fo.write(buf.value.decode())
+    native.check(L.cm_profile_enable(h, 0))
+    fl = C.c_double()
+    by = C.c_double()
+    native.check(L.cm_model_cost(h, nb, C.byref(fl), C.byref(by)))
+    conv3_flops = model.denoiser.conv3_flops(nb) * steps
+    conv3_exec = model.denoiser.conv3_exec_flops(nb) * steps
+    lanes_eff = (lanes if nb >= 8 * lanes else 1) if os.environ.get("CM_PROFILE_LANES") else 1
+    conv_s = un[0] / 1e3                              # (== ms[0] with one lane)
+    ach = conv3_flops / conv_s / 1e12 if conv_s > 0 else 0.0
+    exe = conv3_exec / conv_s / 1e12 if conv_s > 0 else 0.0
+    # matrix-pipe roof of THIS instruction mix: the time the issued instructions need at their peaks (fp32 instructions at
+    # 157.3 TF, 16-bit-operand instructions at 2500 TF -- a six-term fp32 product issues six of the latter) over the class time
+    i32, i16 = model.denoiser.conv3_issue_flops(nb)
+    pipe_s = steps * (i32 / (FP32_MFMA_PEAK_TFLOPS * 1e12) + i16 / (F16_MFMA_PEAK_TFLOPS * 1e12))
+    peak = conv3_exec / pipe_s / 1e12 if pipe_s > 0 else FP32_MFMA_PEAK_TFLOPS
+    return {
+        "kernel": "all 3x3x3 conv launches: conv_wino[_p]_kernel (Winograd F(2x2,3x3) over the in-plane axes, full- and "
+                  "half-resolution layers), conv_qr2_kernel (whole-sample quarter resolution), conv_ups_kernel (parity-form "
+                  "upsample convs, source tile staged once), conv_mfma_kernel<*,*,27> (stride 2), conv_first_kernel, "
+                  "conv_smalln_kernel",
+        "bound": "mfma", "achieved": exe, "peak": peak, "unit": "TFLOP/s",
+        "frac": exe / peak, "traffic": hbm_traffic(),
+        "peak_is": "fp32-equivalent TFLOP/s this launch mix would reach with the matrix pipe never idle: executed fp32-equivalent "
+                   "FLOPs / (FLOPs issued as v_mfma_f32_32x32x2_f32 / %.1f TF + FLOPs issued as v_mfma_f32_32x32x16_{bf16,f16} / "
+                   "%.0f TF); six-term layers issue 6 bf16 products per fp32 product, so `frac` = matrix-pipe busy time at peak "
+                   "rate / measured class time (compare SQ_VALU_MFMA_BUSY_CYCLES in profiles/round3_pmc_summary.csv)"
+                   % (FP32_MFMA_PEAK_TFLOPS, F16_MFMA_PEAK_TFLOPS),
+        "issued_fp32_gflop_per_step": i32 / 1e9, "issued_16bit_gflop_per_step": i16 / 1e9,
+        "matrix_pipe_ms_per_step_at_peak": pipe_s / steps * 1e3,
+        "frac_of_plain_fp32_mfma_peak": exe / FP32_MFMA_PEAK_TFLOPS,
+        "algorithmic_tflops": ach, "algorithmic_frac": ach / FP32_MFMA_PEAK_TFLOPS,
+        "launches": int(cnt[0]), "avg_launch_us": ms[0] * 1e3 / max(1, cnt[0]),
+        "lanes": lanes_eff, "class_busy_ms": un[0], "sum_of_launch_ms": ms[0],
+        "measured_with": "an extra run of the same K steps with HIP events around every launch on its launch stream "
+                         "(events inside the timed runs would add ~1.5 us per launch to `value`), as ONE batch lane -- one "
+                         "launch per layer over the whole batch, the configuration of `python bench.py --lanes 1` and of "
+                         "profiles/round3_kernel_stats.csv -- because two lanes' launches overlap each other (no per-launch "
+                         "duration exists) and recording events from two host threads slows the profiled pass itself by "
+                         "~15 %; `value` runs the default two lanes, which is 4-5 % faster than the sum of these launches. "
+                         "(CM_PROFILE_LANES=1 profiles the lanes: class time = union of the launch intervals, "
+                         "`class_busy_ms`.)  `achieved` counts the fp32-equivalent matrix-core FLOPs actually EXECUTED (Winograd, "
+                         "parity and z-split forms execute fewer than the direct form); `frac` = achieved / peak is the hardware "
+                         "fraction (`peak_is`); `frac_of_plain_fp32_mfma_peak` prices the same FLOPs against the fp32 instruction's "
+                         "157.3 TF alone and exceeds what a pure-fp32 kernel could reach; `algorithmic_*` counts "
+                         "2 x 27 x Ci x Co per voxel as PyTorch counts the reference's nn.Conv3d and can exceed 1 (it "
+                         "is the algorithmic saving, not a roof); rocprofv3 --kernel-trace --stats of this command: "
+                         "profiles/round3_kernel_stats.csv",
+        "executed_gflop_per_launch": conv3_exec / max(1, cnt[0]) / 1e9,
+        "algorithmic_gflop_per_launch": conv3_flops / max(1, cnt[0]) / 1e9,
+        "class_ms_per_step": {k: un[i] / steps for i, k in enumerate(
+            ["conv3x3x3", "conv1x1x1_gemm", "groupnorm_stats", "attention_block", "elementwise"])},
+        "step_algorithmic_gflop": fl.value / 1e9, "step_algorithmic_gbytes": by.value / 1e9,
+    }
+
+
+def measure_sampling(cfg_path, grid, channels, batch, dtype, steps, warmup, repeats, lanes, device=0):
+    """One single-GPU sampling measurement on a FRESH handle (the `secondary` records): K timed steps of the device loop,
+    median of `repeats`, plus the conv-class roofline fraction from a profiled pass."""
+    import torch
+    from crowdmod_ddpm_4d_amd import config as cfgmod, prng
+    from crowdmod_ddpm_4d_amd.ddpm_model import DDPM_model
+    from crowdmod_ddpm_4d_amd.diffusion import DDPM
+    cfg, res = load_cfg(cfg_path)
+    if grid:
+        cfg.MACROPROPS.ROWS, cfg.MACROPROPS.COLS = grid
+        res = cfgmod.resolve(cfg, "DDPM-UNet")
+    model = DDPM_model(cfg, "DDPM-UNet", channels, device=device, seed=42)
+    if dtype != "f32":
+        model.denoiser.set_precision(dtype)
+    sampler = DDPM(timesteps=res.timesteps, scale=res.scale, device=device)
+    shape_p = (batch, channels, res.rows, res.cols, res.past_len)
+    per_p = int(np.prod(shape_p[1:]))
+    past = torch.from_numpy(prng.normal_per_sample(7, "bench/past", np.arange(batch), per_p).reshape(shape_p)).to(torch.device("cuda", device))
+
+    def run(n):
+        return model._generate_ddpm(past, sampler, batch, first_steps=n)[0]
+
+    run(warmup)
+    times = []
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    el = float(np.median(times))
+    rf = profile_roofline(model, run, steps, batch, lanes)
+    model.denoiser._release(keep_training=False)
+    return {"ms_per_step": el / steps * 1e3, "value": steps / el, "unit": "denoise-steps/s", "dtype": dtype, "steps": steps,
+            "repeats": repeats, "batch": batch, "channels": channels, "grid": [res.rows, res.cols],
+            "roofline": {"frac": rf["frac"], "bound": "mfma", "achieved": rf["achieved"], "peak": rf["peak"], "unit": "TFLOP/s",
+                         "avg_launch_us": rf["avg_launch_us"], "launches": rf["launches"]}}
+
+
+def measure_secondary(a):
+    """The other BASELINE configs, measured in the SAME process after the headline (round-3 verdict item 2): each on a fresh
+    handle, >= 50 timed steps, one GPU.  configs[3] / [4] are 8-GPU jobs: one GPU's shard of each is what runs here."""
+    out = {}
+    K = 50
+    specs = [
+        ("configs[3] HERMES-CR-120 28x24, one GPU's shard (B=64, C=3), fp32", "config/HERMES-CR-120.yml", None, 3, 64, "f32"),
+        ("configs[4] ATC_synthetic 24x72, one GPU's shard (B=32, C=3), f16 matrix-core operands", "config/ATC_synthetic.yml", (24, 72), 3, 32, "f16"),
+        ("configs[4] shape in fp32 arithmetic (24x72, B=32, C=3)", "config/ATC_synthetic.yml", (24, 72), 3, 32, "f32"),
+        ("configs[0] shape: ATC 12x36, B=2, C=3 (launch-latency regime)", "config/ATC.yml", None, 3, 2, "f32"),
+    ]
+    for wl, path, grid, ch, B, dt in specs:
+        t0 = time.perf_counter()
+        try:
+            r = measure_sampling(path, grid, ch, B, dt, K, 10, 3, a.lanes)
+            r["workload"] = wl
+            r["wall_s"] = time.perf_counter() - t0
+        except Exception as e:                                    # a secondary record must never take the headline down
+            r = {"workload": wl, "error": "%s: %s" % (type(e).__name__, e)}
+        out[wl.split(" ")[0] + ("_f32" if "fp32 arithmetic" in wl else "")] = r
+    t0 = time.perf_counter()
+    try:
+        ta = argparse.Namespace(batch=128, warmup=3, steps=K, repeats=3)
+        tr = measure_train(ta)
+        out["configs[2]"] = {"workload": tr["config"]["workload"], "ms_per_step": tr["ms_per_step"], "value": tr["value"],
+                             "unit": "train-steps/s", "dtype": tr["dtype"], "steps": K, "repeats": 3, "batch": 128,
+                             "roofline": {k: tr["roofline"][k] for k in ("frac", "bound", "achieved", "peak", "unit")},
+                             "wall_s": time.perf_counter() - t0}
+    except Exception as e:
+        out["configs[2]"] = {"workload": "config/ATC.yml training step, batch 128", "error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+def measure_train(a):
     """BASELINE configs[2]: config/ATC.yml training step (q-sample + UNet fwd with Dropout3d + MSE + bwd + Adam),
-    batch 128, one MI355X, fp32, inputs resident in HBM; one native call per step."""
+    batch 128, one MI355X, fp32, inputs resident in HBM; one native call per step.  Returns the JSON record."""
     from crowdmod_ddpm_4d_amd import native, prng, spec
     from crowdmod_ddpm_4d_amd.diffusion import DDPM
     from crowdmod_ddpm_4d_amd.unet import UNet
@@ -166,7 +313,7 @@ def run_train(a):
     fwd_flops, fwd_bytes = net.cost(B)
     ach = 3 * fwd_flops / dt_s / 1e12
     exe = 3 * net.exec_flops(B) / dt_s / 1e12
-    print(json.dumps({
+    rec = ({
         "metric": "train-steps/sec (q-sample + UNet fwd + MSE + bwd + Adam) at ATC [B,3,T,H,W]", "value": 1.0 / dt_s,
         "unit": "train-steps/s (each over a batch of %d windows)" % B, "n_gpus": 1, "steps": steps, "warmup": a.warmup,
         "ms_per_step": dt_s * 1e3, "repeat_ms_per_step": [x * 1e3 for x in times], "higher_is_better": True, "scaling": "weak",
@@ -187,7 +334,13 @@ def run_train(a):
                              "although ~70 % of the forward / data-gradient FLOPs are issued as six bf16 products each (2.7x the fp32 "
                              "rate): a mixed-instruction roof like the sampling line's needs per-kernel FLOP counts of the backward, "
                              "which the library does not export"},
-        "loss_first": losses[0], "loss_last": losses[-1]}))
+        "loss_first": losses[0], "loss_last": losses[-1]})
+    net._release(keep_training=False)
+    return rec
+
+
+def run_train(a):
+    print(json.dumps(measure_train(a)))
 
 
 def main():
@@ -205,10 +358,13 @@ def main():
                     "BASELINE configs[3]'s per-GPU shard; its own JSON line)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--lanes", type=int, default=2, help="batch lanes on separate HIP streams inside one rank (CM_LANES): the B "
-                    "chains run as `lanes` independent half-batches whose launches overlap (bit-identical results); 1 = one "
-                    "launch per layer")
+    ap.add_argument("--lanes", type=int, default=None, help="batch lanes on separate HIP streams inside one rank (default: the "
+                    "caller's CM_LANES, else 2): the B chains run as `lanes` independent half-batches whose launches overlap "
+                    "(bit-identical results); 1 = one launch per layer")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object (the other BASELINE configs, N = 1 only)")
     a = ap.parse_args()
+    if a.lanes is None:
+        a.lanes = int(os.environ.get("CM_LANES", "2") or 2)
     os.environ["CM_LANES"] = str(max(1, a.lanes))   # read once by the library at the first loop call
     if a.mode == "train":
         return run_train(a)
@@ -291,75 +447,7 @@ def main():
     # ---- roofline of the dominant kernel class: a profiled re-run of the same K steps ------
     roofline = None
     if not a.no_profile and rank == 0:
-        L = native.lib()
-        h = model.denoiser._handle
-        native.check(L.cm_profile_enable(h, 1))
-        run(steps)
-        torch.cuda.synchronize()
-        ms = (C.c_float * 8)()
-        cnt = (C.c_int64 * 8)()
-        native.check(L.cm_profile_read(h, ms, cnt))
-        un = (C.c_float * 8)()
-        native.check(L.cm_profile_read_union(h, un))     # per class: union of its launch intervals over the batch lanes
-        if os.environ.get("CM_BENCH_REPORT"):
-            buf = C.create_string_buffer(1 << 16)
-            native.check(L.cm_profile_report(h, buf, len(buf)))
-            with open(os.environ["CM_BENCH_REPORT"], "w") as fo:
-                fo.write(buf.value.decode())
-        native.check(L.cm_profile_enable(h, 0))
-        fl = C.c_double()
-        by = C.c_double()
-        nb = hi - lo
-        native.check(L.cm_model_cost(h, nb, C.byref(fl), C.byref(by)))
-        conv3_flops = model.denoiser.conv3_flops(nb) * steps
-        conv3_exec = model.denoiser.conv3_exec_flops(nb) * steps
-        lanes_eff = (a.lanes if (hi - lo) >= 8 * a.lanes else 1) if os.environ.get("CM_PROFILE_LANES") else 1
-        conv_s = un[0] / 1e3                              # (== ms[0] with one lane)
-        ach = conv3_flops / conv_s / 1e12 if conv_s > 0 else 0.0
-        exe = conv3_exec / conv_s / 1e12 if conv_s > 0 else 0.0
-        # matrix-pipe roof of THIS instruction mix: the time the issued instructions need at their peaks (fp32 instructions at
-        # 157.3 TF, 16-bit-operand instructions at 2500 TF -- a six-term fp32 product issues six of the latter) over the class time
-        i32, i16 = model.denoiser.conv3_issue_flops(nb)
-        pipe_s = steps * (i32 / (FP32_MFMA_PEAK_TFLOPS * 1e12) + i16 / (F16_MFMA_PEAK_TFLOPS * 1e12))
-        peak = conv3_exec / pipe_s / 1e12 if pipe_s > 0 else FP32_MFMA_PEAK_TFLOPS
-        roofline = {
-            "kernel": "all 3x3x3 conv launches: conv_wino[_p]_kernel (Winograd F(2x2,3x3) over the in-plane axes, full- and "
-                      "half-resolution layers), conv_qr2_kernel (whole-sample quarter resolution), conv_ups_kernel (parity-form "
-                      "upsample convs, source tile staged once), conv_mfma_kernel<*,*,27> (stride 2), conv_first_kernel, "
-                      "conv_smalln_kernel",
-            "bound": "mfma", "achieved": exe, "peak": peak, "unit": "TFLOP/s",
-            "frac": exe / peak, "traffic": hbm_traffic(),
-            "peak_is": "fp32-equivalent TFLOP/s this launch mix would reach with the matrix pipe never idle: executed fp32-equivalent "
-                       "FLOPs / (FLOPs issued as v_mfma_f32_32x32x2_f32 / %.1f TF + FLOPs issued as v_mfma_f32_32x32x16_{bf16,f16} / "
-                       "%.0f TF); six-term layers issue 6 bf16 products per fp32 product, so `frac` = matrix-pipe busy time at peak "
-                       "rate / measured class time (compare SQ_VALU_MFMA_BUSY_CYCLES in profiles/round3_pmc_summary.csv)"
-                       % (FP32_MFMA_PEAK_TFLOPS, F16_MFMA_PEAK_TFLOPS),
-            "issued_fp32_gflop_per_step": i32 / 1e9, "issued_16bit_gflop_per_step": i16 / 1e9,
-            "matrix_pipe_ms_per_step_at_peak": pipe_s / steps * 1e3,
-            "frac_of_plain_fp32_mfma_peak": exe / FP32_MFMA_PEAK_TFLOPS,
-            "algorithmic_tflops": ach, "algorithmic_frac": ach / FP32_MFMA_PEAK_TFLOPS,
-            "launches": int(cnt[0]), "avg_launch_us": ms[0] * 1e3 / max(1, cnt[0]),
-            "lanes": lanes_eff, "class_busy_ms": un[0], "sum_of_launch_ms": ms[0],
-            "measured_with": "an extra run of the same K steps with HIP events around every launch on its launch stream "
-                             "(events inside the timed runs would add ~1.5 us per launch to `value`), as ONE batch lane -- one "
-                             "launch per layer over the whole batch, the configuration of `python bench.py --lanes 1` and of "
-                             "profiles/round3_kernel_stats.csv -- because two lanes' launches overlap each other (no per-launch "
-                             "duration exists) and recording events from two host threads slows the profiled pass itself by "
-                             "~15 %; `value` runs the default two lanes, which is 4-5 % faster than the sum of these launches. "
-                             "(CM_PROFILE_LANES=1 profiles the lanes: class time = union of the launch intervals, "
-                             "`class_busy_ms`.)  `achieved` counts the fp32-equivalent matrix-core FLOPs actually EXECUTED (Winograd, "
-                             "parity and z-split forms execute fewer than the direct form); `frac` = achieved / peak is the hardware "
-                             "fraction (`peak_is`); `frac_of_plain_fp32_mfma_peak` prices the same FLOPs against the fp32 instruction's "
-                             "157.3 TF alone and exceeds what a pure-fp32 kernel could reach; `algorithmic_*` counts "
-                             "2 x 27 x Ci x Co per voxel as PyTorch counts the reference's nn.Conv3d and can exceed 1 (it "
-                             "is the algorithmic saving, not a roof); rocprofv3 --kernel-trace --stats of this command: "
-                             "profiles/round3_kernel_stats.csv",
-            "executed_gflop_per_launch": conv3_exec / max(1, cnt[0]) / 1e9,
-            "algorithmic_gflop_per_launch": conv3_flops / max(1, cnt[0]) / 1e9,
-            "class_ms_per_step": {k: un[i] / steps for i, k in enumerate(
-                ["conv3x3x3", "conv1x1x1_gemm", "groupnorm_stats", "attention_block", "elementwise"])},
-            "step_algorithmic_gflop": fl.value / 1e9, "step_algorithmic_gbytes": by.value / 1e9,
-        }
+        roofline = profile_roofline(model, run, steps, hi - lo, a.lanes)
     if dist is not None:
         dist.barrier()
 
@@ -397,6 +485,10 @@ def main():
             out["roofline"] = roofline
         if cpu:
             out["cpu_baseline"] = cpu
+        # the other BASELINE configs, same process, fresh handles (default headline run at N = 1 only)
+        if world == 1 and not a.no_secondary and a.dtype == "f32" and not a.grid and not a.config and not a.batch and a.channels == 4:
+            model.denoiser._release(keep_training=False)
+            out["secondary"] = measure_secondary(a)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -611,3 +611,37 @@ def test_motion_feature_metrics_match_the_reference_extractor():
     assert c[0] == 1e-2 and abs(d[0] + np.log(1e-2)) < 1e-15
     only = metrics.motion_feature_tables(g["pred"], g["gt"], 1, 4, 0.5, mse_metric=False, bhatt_metrics=True)
     assert only["MF_MSE"] is None and only["MF_BHATT_DIST"] is not None
+
+
+def test_bench_secondary_object_has_one_record_per_other_baseline_config(monkeypatch):
+    """bench.py's `secondary` object (round-3 verdict item 2): one record per BASELINE config besides the headline, each with
+    ms_per_step / value / dtype / workload / roofline.frac; a failing secondary measurement becomes an `error` record and
+    never takes the headline line down; the whole object serialises."""
+    import argparse
+    import json
+    import bench
+    calls = []
+
+    def fake_sampling(cfg_path, grid, channels, batch, dtype, steps, warmup, repeats, lanes, device=0):
+        calls.append((cfg_path, grid, channels, batch, dtype, steps))
+        if batch == 2:
+            raise RuntimeError("boom")
+        return {"ms_per_step": 2.0, "value": 500.0, "unit": "denoise-steps/s", "dtype": dtype, "steps": steps, "repeats": repeats,
+                "batch": batch, "channels": channels, "grid": list(grid or (12, 36)), "roofline": {"frac": 0.3}}
+
+    def fake_train(a):
+        assert a.batch == 128 and a.steps >= 50
+        return {"config": {"workload": "train"}, "ms_per_step": 12.0, "value": 83.0, "dtype": "f32",
+                "roofline": {"frac": 0.4, "bound": "mfma", "achieved": 60.0, "peak": 157.3, "unit": "TFLOP/s"}}
+
+    monkeypatch.setattr(bench, "measure_sampling", fake_sampling)
+    monkeypatch.setattr(bench, "measure_train", fake_train)
+    sec = bench.measure_secondary(argparse.Namespace(lanes=2))
+    assert set(sec) == {"configs[3]", "configs[4]", "configs[4]_f32", "configs[0]", "configs[2]"}
+    assert ("config/HERMES-CR-120.yml", None, 3, 64, "f32", 50) in calls
+    assert ("config/ATC_synthetic.yml", (24, 72), 3, 32, "f16", 50) in calls
+    for k in ("configs[3]", "configs[4]", "configs[4]_f32", "configs[2]"):
+        r = sec[k]
+        assert r["ms_per_step"] > 0 and r["value"] > 0 and r["dtype"] in ("f32", "f16") and r["workload"] and 0 < r["roofline"]["frac"] <= 1
+    assert "boom" in sec["configs[0]"]["error"]
+    json.dumps(sec)
