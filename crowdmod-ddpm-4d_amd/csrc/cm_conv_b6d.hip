@@ -1,0 +1,534 @@
+// Direct 3x3x3 stride-1 convolution in fp32 arithmetic on the bf16 matrix instruction: every fp32 product is formed from
+// exact three-way bf16 splits of both operands (six cross terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate -- the
+// arithmetic of DESIGN.md section 4, same as the six-term Winograd / quarter-resolution / upsample kernels).  It serves the
+// stride-1 nn.Conv3d of the full-resolution ResnetBlocks (/root/reference/models/backbones/layers.py:32,43,57,70) in
+// the fp32 plan.
+//
+// Why a direct form next to the six-term Winograd kernel (round-3 verdict, item 1b): in the Winograd form every fp32 value is
+// split once per FREQUENCY COMPONENT (16 per 2x2 outputs: 4 splits per output voxel and channel) after a B^T d B transform,
+// and each wave streams its own weight fragments (3 KB per six matrix instructions) -- 8 vector instructions per matrix
+// instruction, phases that do not overlap, matrix pipe 0.25 busy.  Here the split is paid once per STAGED input element
+// (halo ratio 2.25 per output voxel, no transforms), a weight fragment feeds MBW row blocks, and the chunk loop is
+// ~1.5 vector instructions per matrix instruction: the kernel issues 2.25x the matrix work into a pipe that was 75 % idle.
+// tools/ubench/b6_loop.hip measured the main loop's ceiling: weight fragments streamed per wave from L1 / L2 cap the matrix
+// pipe at 0.53-0.68 with one row block per wave, 0.76-0.79 with two, 0.81-0.84 with three (LDS-shared fragments: 0.75).
+//
+//   * workgroup = NW waves, one output box of <= 32 NW MBW voxels x 32 NB channels of ONE sample; wave w owns the row blocks
+//     [w MBW, (w+1) MBW) and all NB column blocks: no cross-wave reduction;
+//   * per 16-channel chunk every REAL halo voxel is normalised (GroupNorm affine + SiLU [+ Dropout3d multiplier]) once, split
+//     into hi / mid / lo bf16 terms and written to LDS as A[k half hh][halo row][term][4 dwords]: a lane's three A fragments
+//     are 16-byte reads at immediate offsets 0 / 16 / 32 from one address, conflict-free when the 16 rows of a service group
+//     of ds_read_b128 are distinct mod 16 (the host picks the row order of a tile accordingly: conv_b6d_tables); rows of
+//     zero-padding voxels are zeroed once per workgroup and never written;
+//   * per tap 6 MBW NB matrix instructions per wave; weight fragments stream global -> VGPR through a ring of 3 taps that runs
+//     across chunk boundaries (pack_b6d: [n tile][chunk][tap][nb][term][lane] 16 B);
+//   * the block's 1x1x1 skip convolution rides along as extra chunks (centre tap, raw input, same six terms);
+//   * epilogue of the direct kernels: bias, time-embedding row, residual, fp32 channels-last store, GroupNorm statistics per
+//     (row block, channel) in the slot format of gn_finalize.
+#include "cm_kernels.h"
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+namespace cm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float silu_d(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// tabS[p][NSP][2]: staging list of tile position p -- (in-sample source voxel, LDS row) of its i-th REAL halo voxel, (-1, 0) beyond
+//                  the list;   tabM[p][32 NW MBW][2]: row m -> (LDS row of its voxel at tap (0,0,0), in-sample output voxel or -1).
+// HVP: LDS rows per k half (>= halo voxels, = 4 mod 8);  PY, PZ: halo pitches in rows (tap (dz,dy,dx) = row + dz PZ + dy PY + dx).
+#ifndef CM_B6D_ABL
+#define CM_B6D_ABL 0         // compile-time ablations (experiments only; results are wrong): 1 no weight refill, 2 no halo reload,
+#endif                       // 4 no staging after chunk 0, 8 one matrix instruction of six, 16 no epilogue, 32 no A reads after tap 0
+template <int NW, int MBW, int NB>
+__global__ __launch_bounds__(64 * NW, 2) void conv_b6d_kernel(const ConvArgs a, const int *__restrict__ tabS,
+                                                                           const int *__restrict__ tabM, int NSP, int HVP, int PY, int PZ,
+                                                                           int ntp) {
+  constexpr int NT = 64 * NW;
+  constexpr int NLD = 10;                        // staging items (voxel, channel quad) per thread and chunk: 4 NSP / NT <= 10
+  constexpr int RW = 12;                         // LDS row: 3 terms x 4 dwords (8 bf16 of one k half)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *A = lds;                                // [2 hh][HVP][RW]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  int tile = blockIdx.x;
+  if (!(gridDim.x & 7) && !(a.dbg & 4096)) tile = (tile & 7) * (int)(gridDim.x >> 3) + (tile >> 3);   // XCD-aware order (cm_conv.hip)
+  const int b = tile / ntp, p = tile - b * ntp;
+  const int nt = blockIdx.y;
+  const unsigned Vs = (unsigned)(a.Zs * a.Ys * a.Xs);
+
+  // ---- geometry from the host tables -------------------------------------------------------------------------------
+  const int nit = (4 * NSP + NT - 1) / NT;        // items per thread (its channel quad q = tid & 3 is the same for all)
+  const int q = tid & 3;
+  int soff[NLD], srow[NLD];
+  unsigned sok = 0;
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int i = (tid >> 2) + (NT / 4) * k;
+    int o = -1, rw = 0;
+    if (k < nit && i < NSP) {
+      o = tabS[((size_t)p * NSP + i) * 2];
+      rw = tabS[((size_t)p * NSP + i) * 2 + 1];
+    }
+    sok |= (o >= 0 ? 1u : 0u) << k;
+    soff[k] = o >= 0 ? o : 0;
+    // LDS dword offset of this item's 8 bytes: k half q >> 1, row, (+ 4 term), 2 (q & 1)
+    srow[k] = ((q >> 1) * HVP + rw) * RW + 2 * (q & 1);
+  }
+  int abase[MBW], ovox[MBW];                       // per lane: LDS dword offset of the row's voxel (tap 0,0,0; its k half), output voxel
+#pragma unroll
+  for (int j = 0; j < MBW; ++j) {
+    const int m = (wave * MBW + j) * 32 + r;
+    abase[j] = (hh * HVP + tabM[((size_t)p * 32 * NW * MBW + m) * 2]) * RW;
+    ovox[j] = tabM[((size_t)p * 32 * NW * MBW + m) * 2 + 1];
+  }
+  const int n16 = (a.C0 + a.C1) >> 4, n0 = a.C0 >> 4;                 // 16-channel chunks of the main input
+  const int ns16 = a.s2w ? (a.s2C0 + a.s2C1) >> 4 : 0, ns0 = a.s2C0 >> 4;   // ... of the fused skip input (raw, centre tap)
+  const int nch = n16 + ns16;
+  const int Ctot = a.C0 + a.C1;
+
+  // zero the whole image once: rows of zero-padding voxels are never written afterwards
+  for (int i = tid; i < 2 * HVP * (RW / 4); i += NT) *reinterpret_cast<f32x4 *>(A + 4 * i) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x16 acc[MBW][NB];
+#pragma unroll
+  for (int j = 0; j < MBW; ++j)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
+
+  // weights: main  [nt][chunk][tap 27][nb][term][lane] 16 B, skip [nt][chunk][nb][term][lane] 16 B
+  const f32x4 *wmain = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * n16 * 27 * NB * 3 * 64 + lane;
+  const f32x4 *wskip = a.s2w ? reinterpret_cast<const f32x4 *>(a.s2w) + (size_t)nt * ns16 * NB * 3 * 64 + lane : nullptr;
+
+  // ---- loads of chunk c (main: GroupNorm rows too) -------------------------------------------------------------------
+  f32x4 ld[NLD], scn = {1.f, 1.f, 1.f, 1.f}, shn = {0.f, 0.f, 0.f, 0.f}, pmn = {1.f, 1.f, 1.f, 1.f};
+  auto issue = [&](int c) {
+    const float *base;
+    int Cn;
+    if (c < n16) {
+      const bool s0 = c < n0;
+      Cn = s0 ? a.C0 : a.C1;
+      base = (s0 ? a.src0 + c * 16 : a.src1 + (c - n0) * 16) + (size_t)b * Vs * Cn;
+      if (a.gn) {
+        const float *gp = a.gn + (size_t)b * 2 * Ctot + c * 16 + 4 * q;
+        scn = *reinterpret_cast<const f32x4 *>(gp);
+        shn = *reinterpret_cast<const f32x4 *>(gp + Ctot);
+      }
+      if (a.pm) pmn = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + c * 16 + 4 * q);
+    } else {
+      const int cs = c - n16;
+      const bool s0 = cs < ns0;
+      Cn = s0 ? a.s2C0 : a.s2C1;
+      base = (s0 ? a.s2src0 + cs * 16 : a.s2src1 + (cs - ns0) * 16) + (size_t)b * Vs * Cn;
+    }
+    const unsigned cb = (unsigned)Cn * 4u, q16 = 16u * (unsigned)q;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      if (k < nit) ld[k] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(base) + (__umul24((unsigned)soff[k], cb) + q16));
+  };
+  auto stage = [&](int c) {
+    const bool main = c < n16;
+    const f32x4 sc = scn, sh = shn, pm = pmn;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      if (k < nit) {
+        f32x4 w = ld[k];
+        if (main && a.gn && !(a.dbg & 128)) {
+          w = w * sc + sh;
+          if (a.silu) { w[0] = silu_d(w[0]); w[1] = silu_d(w[1]); w[2] = silu_d(w[2]); w[3] = silu_d(w[3]); }
+        }
+        if (main && a.pm) w = w * pm;
+        cm_u32x2_t t3[3];
+        cm_split3_bf16(w, t3);                    // hi / mid / lo terms, exact remainders
+        if ((sok >> k) & 1u) {
+#pragma unroll
+          for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<cm_u32x2_t *>(A + srow[k] + 4 * tm) = t3[tm];
+        }
+      }
+  };
+  issue(0);
+  const int n = nt * 32 * NB + r;                 // (+ 32 nb)
+  float bias_pre[NB], tv_pre[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int nn = n + 32 * nb < a.Co ? n + 32 * nb : 0;
+    bias_pre[nb] = a.bias[nn];
+    tv_pre[nb] = a.temb ? a.temb[(size_t)a.tidx[b] * a.temb_stride + nn] : 0.f;
+  }
+  // weight ring: RD taps ahead, running across chunk boundaries (27 % RD == 0: a chunk always starts on slot 0)
+  constexpr int RD = 3;
+  f32x4 bw[RD][NB][3];
+  if (n16 > 0) {
+#pragma unroll
+    for (int t = 0; t < RD; ++t)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) bw[t][nb][tm] = wmain[(size_t)((t * NB + nb) * 3 + tm) * 64];
+  }
+  __syncthreads();                                // zero image complete before the first rows are written
+
+  // (A term, B term), small products first: hi = 0, mid = 1, lo = 2
+  constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+  for (int c = 0; c < nch; ++c) {
+    if (!((CM_B6D_ABL & 4) && c > 0)) stage(c);
+    __syncthreads();                              // image of chunk c complete
+    if (c + 1 < nch && !(CM_B6D_ABL & 2)) issue(c + 1);   // next chunk's loads: in flight under this matrix phase
+    if (a.dbg & 2) { __syncthreads(); continue; }
+    if (c < n16) {
+      const f32x4 *wc = wmain + (size_t)c * 27 * NB * 3 * 64;
+      const bool more_c = c + 1 < n16;
+      f32x4 af[MBW][3], afn[MBW][3];
+#pragma unroll
+      for (int j = 0; j < MBW; ++j)
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) af[j][tm] = *reinterpret_cast<const f32x4 *>(A + abase[j] + 4 * tm);
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        if (t + 1 < 27 && !(CM_B6D_ABL & 32)) {
+          const int t1 = t + 1, dz = t1 / 9, dy = (t1 / 3) % 3, dx = t1 % 3;
+          const int toff = (dz * PZ + dy * PY + dx) * RW;
+#pragma unroll
+          for (int j = 0; j < MBW; ++j)
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) afn[j][tm] = *reinterpret_cast<const f32x4 *>(A + abase[j] + toff + 4 * tm);
+        }
+#pragma unroll
+        for (int j = 0; j < MBW; ++j)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int u = 0; u < ((CM_B6D_ABL & 8) ? 1 : 6); ++u)
+              acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j][TA[u]]),
+                                                                   __builtin_bit_cast(bf16x8, bw[t % RD][nb][TB[u]]), acc[j][nb], 0, 0, 0);
+        // refill this ring slot AFTER the matrix instructions that read it (tap t + RD of this chunk or of the next one); the
+        // fence keeps the refill here: without it the compiler sinks the load to just before its first use
+        {
+          const int tn = t + RD;
+          const bool wraps = tn >= 27;
+          if ((!wraps || more_c) && !(CM_B6D_ABL & 1)) {
+            const f32x4 *wn = wc + (size_t)((wraps ? 27 * NB * 3 : 0) + ((wraps ? tn - 27 : tn) * NB) * 3) * 64;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+              for (int tm = 0; tm < 3; ++tm) bw[t % RD][nb][tm] = wn[(size_t)(nb * 3 + tm) * 64];
+          }
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < MBW; ++j)
+#pragma unroll
+          for (int tm = 0; tm < 3; ++tm) af[j][tm] = (CM_B6D_ABL & 32) ? af[j][tm] : afn[j][tm];
+      }
+    } else {
+      // fused 1x1x1 skip conv (layers.py:46,74): centre tap of the raw block input
+      const f32x4 *wc = wskip + (size_t)(c - n16) * NB * 3 * 64;
+      const int toff = (PZ + PY + 1) * RW;
+      f32x4 af[MBW][3], w4[NB][3];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) w4[nb][tm] = wc[(size_t)(nb * 3 + tm) * 64];
+#pragma unroll
+      for (int j = 0; j < MBW; ++j)
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) af[j][tm] = *reinterpret_cast<const f32x4 *>(A + abase[j] + toff + 4 * tm);
+#pragma unroll
+      for (int j = 0; j < MBW; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int u = 0; u < 6; ++u)
+            acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j][TA[u]]),
+                                                                 __builtin_bit_cast(bf16x8, w4[nb][TB[u]]), acc[j][nb], 0, 0, 0);
+    }
+    __syncthreads();                              // every wave has read chunk c: the image may be overwritten
+  }
+
+  // ---- epilogue: lane (r, hh) of block (j, nb) holds rows (e & 3) + 8 (e >> 2) + 4 hh, channel n + 32 nb --------------------
+  // the output voxel of a row lives in the lane with that r: fetch it with a wave shuffle (ds_bpermute)
+  if ((a.dbg & 4) || (CM_B6D_ABL & 16)) {
+    float sgn = 0.f;
+#pragma unroll
+    for (int j = 0; j < MBW; ++j)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) sgn += acc[j][nb][0] + acc[j][nb][7];
+    if (sgn == 123.456f) a.out[0] = 1.f;
+    return;
+  }
+  float *const outb = a.out + (size_t)b * (size_t)(a.Zo * a.Yo * a.Xo) * a.out_cs;
+  const float *const resb = a.resid ? a.resid + (size_t)b * (size_t)(a.Zo * a.Yo * a.Xo) * a.res_cs : nullptr;
+  const int ns = ntp * NW * MBW;
+#pragma unroll
+  for (int j = 0; j < MBW; ++j) {
+    int orow[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) orow[e] = __shfl(ovox[j], (e & 3) + 8 * (e >> 2) + 4 * hh);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int nn = n + 32 * nb;
+      const bool nok = nn < a.Co;
+      float rs[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) rs[e] = acc[j][nb][e] + bias_pre[nb] + tv_pre[nb];
+      if (resb) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rs[e] += resb[(size_t)(orow[e] >= 0 ? orow[e] : 0) * a.res_cs + (nok ? nn : 0)];
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (nok && orow[e] >= 0) outb[(size_t)orow[e] * a.out_cs + nn] = rs[e];
+      if (a.stat_part) {
+        float s1 = 0.f, cnt = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (orow[e] >= 0) { s1 += rs[e]; cnt += 1.f; }
+        s1 += __shfl_xor(s1, 32);
+        cnt += __shfl_xor(cnt, 32);
+        const float mean = cnt > 0.f ? s1 / cnt : 0.f;
+        float q2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (orow[e] >= 0) { const float dd = rs[e] - mean; q2 += dd * dd; }
+        q2 += __shfl_xor(q2, 32);
+        const int slot = p * (NW * MBW) + wave * MBW + j;
+        if (hh == 0 && nok) {
+          float *sp2 = a.stat_part + (((size_t)b * ns + slot) * a.stat_C + nn) * 2;
+          sp2[0] = mean;
+          sp2[1] = q2;
+        }
+        if (lane == 0 && nn == 0) a.stat_cnt[(size_t)b * ns + slot] = cnt;
+      }
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+// Tile = bz x by x bx output voxels (divisors of the grid), rows = bz by bx <= 32 NW MBW with NW MBW row blocks; NW in {2, 4}
+// waves, MBW in {1, 2, 3} row blocks per wave.  Preference: two row blocks per wave (a weight fragment feeds two of them: the
+// matrix pipe's ceiling is 0.76-0.79 instead of 0.53-0.68, tools/ubench/b6_loop.hip), full blocks, small halo, many workgroups.
+bool conv_b6d_pick(int Z, int Y, int X, int *bz, int *by, int *bx, int *nw, int *mbw) {
+  double best = 0;
+  for (int w : {2, 4})
+    for (int m = 1; m <= 2; ++m)
+      for (int z = 1; z <= Z; ++z)
+        for (int y = 1; y <= Y; ++y)
+          for (int x = 1; x <= X; ++x) {
+            if (Z % z || Y % y || X % x) continue;
+            const int rows = z * y * x, cap = 32 * w * m;
+            if (rows > cap || rows <= cap - 32 * w) continue;       // every wave's LAST block at least partly filled
+            const int hv = (z + 2) * (y + 2) * (x + 2);
+            const int hreal = std::min(z + 2, Z) * std::min(y + 2, Y) * std::min(x + 2, X);
+            if (4 * hreal > 10 * 64 * w) continue;                    // staging items per thread (NLD)
+            const double eff = (double)rows / cap, halo = (double)rows / hreal;
+            const double lds = (double)hv * 96.0;
+            const double wgs = std::min(4.0, std::floor(160.0 * 1024 / lds)) * w;   // waves per CU by LDS
+            const double score = eff * (0.4 + 0.6 * halo) * (m == 2 ? 1.0 : 0.8) * (wgs >= 8 ? 1.0 : 0.8) * (w == 2 ? 1.0 : 0.97);
+            if (score > best) { best = score; *bz = z; *by = y; *bx = x; *nw = w; *mbw = m; }
+          }
+  return best > 0;
+}
+
+// Row order of a tile: the 16 rows that one service group of ds_read_b128 reads ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a
+// 32-row block) must sit on 16 different 48-byte slots mod 16 rows.  Try the six nesting orders of (z, y, x) and keep the one with
+// the fewest conflicts (0 for the reference grids' 8 x 4 x 4 tile: y outermost).  `rowvox[m]` = (z, y, x) packed as z<<16|y<<8|x.
+static int b6d_row_order(int bz, int by, int bx, int PY, int PZ, std::vector<int> &rowvox) {
+  static const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+  const int dim[3] = {bz, by, bx};
+  const int rows = bz * by * bx;
+  int bestc = 1 << 30;
+  std::vector<int> cand((size_t)rows);
+  for (int pi = 0; pi < 6; ++pi) {
+    const int o0 = perm[pi][0], o1 = perm[pi][1], o2 = perm[pi][2];     // outer .. inner axis
+    int m = 0;
+    for (int i0 = 0; i0 < dim[o0]; ++i0)
+      for (int i1 = 0; i1 < dim[o1]; ++i1)
+        for (int i2 = 0; i2 < dim[o2]; ++i2, ++m) {
+          int c[3];
+          c[o0] = i0; c[o1] = i1; c[o2] = i2;
+          cand[(size_t)m] = (c[0] << 16) | (c[1] << 8) | c[2];
+        }
+    int conf = 0;
+    for (int blk = 0; blk * 32 < rows; ++blk)
+      for (int g = 0; g < 2; ++g) {
+        int cnt[16] = {0};
+        for (int rr = 0; rr < 32; ++rr) {
+          const bool g0 = rr < 4 || (rr >= 12 && rr < 16) || (rr >= 20 && rr < 28);
+          if (g0 != (g == 0) || blk * 32 + rr >= rows) continue;
+          const int v = cand[(size_t)(blk * 32 + rr)];
+          const int h = (v >> 16) * PZ + ((v >> 8) & 255) * PY + (v & 255);
+          conf += cnt[h & 15]++;
+        }
+      }
+    if (conf < bestc) { bestc = conf; rowvox = cand; }
+  }
+  return bestc;
+}
+
+struct B6dTabs { int *tS = nullptr, *tM = nullptr; int NSP = 0, HVP = 0, PY = 0, PZ = 0, ntp = 0, conflicts = 0; };
+// host-only table builder (also used by the self-test)
+void conv_b6d_tables(int Z, int Y, int X, int bz, int by, int bx, int nw, int mbw, std::vector<int> &tS, std::vector<int> &tM,
+                     int *NSP, int *HVP, int *PY_, int *PZ_, int *ntp_, int *conflicts) {
+  const int HZ = bz + 2, HY = by + 2, HX = bx + 2, HV = HZ * HY * HX;
+  const int PY = HX, PZ = HY * HX;
+  const int ntz = Z / bz, nty = Y / by, ntx = X / bx, ntp = ntz * nty * ntx;
+  const int rows = bz * by * bx, MR = 32 * nw * mbw;
+  std::vector<int> rowvox;
+  const int conf = b6d_row_order(bz, by, bx, PY, PZ, rowvox);
+  int hvp = HV;
+  while ((hvp & 7) != 4) ++hvp;
+  // staging lists: real voxels only; NSP = longest list
+  int nsp = 0;
+  std::vector<std::vector<int>> lists((size_t)ntp);
+  for (int tz = 0; tz < ntz; ++tz)
+    for (int ty = 0; ty < nty; ++ty)
+      for (int tx = 0; tx < ntx; ++tx) {
+        const int p = (tz * nty + ty) * ntx + tx;
+        const int z0 = tz * bz, y0 = ty * by, x0 = tx * bx;
+        for (int h = 0; h < HV; ++h) {
+          const int hz = h / (HY * HX), rem = h % (HY * HX), hy = rem / HX, hx = rem % HX;
+          const int cz = z0 - 1 + hz, cy = y0 - 1 + hy, cx = x0 - 1 + hx;
+          if (cz >= 0 && cz < Z && cy >= 0 && cy < Y && cx >= 0 && cx < X) {
+            lists[(size_t)p].push_back((cz * Y + cy) * X + cx);
+            lists[(size_t)p].push_back(h);
+          }
+        }
+        nsp = std::max(nsp, (int)lists[(size_t)p].size() / 2);
+      }
+  tS.assign((size_t)ntp * nsp * 2, 0);
+  tM.assign((size_t)ntp * MR * 2, 0);
+  for (int p = 0; p < ntp; ++p) {
+    for (int i = 0; i < nsp; ++i) {
+      const bool have = 2 * i < (int)lists[(size_t)p].size();
+      tS[((size_t)p * nsp + i) * 2] = have ? lists[(size_t)p][(size_t)2 * i] : -1;
+      tS[((size_t)p * nsp + i) * 2 + 1] = have ? lists[(size_t)p][(size_t)2 * i + 1] : 0;
+    }
+    const int tz = p / (nty * ntx), ty = (p / ntx) % nty, tx = p % ntx;
+    for (int m = 0; m < MR; ++m) {
+      int hidx = 0, ov = -1;
+      if (m < rows) {
+        const int v = rowvox[(size_t)m], z = v >> 16, y = (v >> 8) & 255, x = v & 255;
+        hidx = z * PZ + y * PY + x;                // halo row of tap (0, 0, 0) for this output voxel
+        ov = ((tz * bz + z) * Y + (ty * by + y)) * X + (tx * bx + x);
+      }
+      tM[((size_t)p * MR + m) * 2] = hidx;
+      tM[((size_t)p * MR + m) * 2 + 1] = ov;
+    }
+  }
+  *NSP = nsp; *HVP = hvp; *PY_ = PY; *PZ_ = PZ; *ntp_ = ntp;
+  if (conflicts) *conflicts = conf;
+}
+
+static hipError_t b6d_tabs_get(const ConvArgs &a, int nw, int mbw, B6dTabs *out) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int, int, int, int, int, int, int>, B6dTabs> cache;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const auto key = std::make_tuple(dev, a.Zo, a.Yo, a.Xo, a.bz, a.by, a.bx, nw, mbw);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    std::vector<int> tS, tM;
+    B6dTabs t;
+    conv_b6d_tables(a.Zo, a.Yo, a.Xo, a.bz, a.by, a.bx, nw, mbw, tS, tM, &t.NSP, &t.HVP, &t.PY, &t.PZ, &t.ntp, &t.conflicts);
+    hipError_t e = hipMalloc((void **)&t.tS, tS.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&t.tM, tM.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(t.tS, tS.data(), tS.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t.tM, tM.data(), tM.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    it = cache.emplace(key, t).first;
+  }
+  *out = it->second;
+  return hipSuccess;
+}
+
+bool conv_b6d_ok(const ConvArgs &a, int nw, int mbw) {
+  if (!(a.ntaps == 27 && a.stride == 1 && !a.par && !a.ups && a.C0 % 16 == 0 && a.C1 % 16 == 0 && a.Co % 32 == 0 && a.Zs == a.Zo &&
+        a.Ys == a.Yo && a.Xs == a.Xo && (nw == 2 || nw == 4) && mbw >= 1 && mbw <= 2 && a.bz > 0 && a.by > 0 && a.bx > 0 &&
+        a.Zo % a.bz == 0 && a.Yo % a.by == 0 && a.Xo % a.bx == 0 && a.bz * a.by * a.bx <= 32 * nw * mbw &&
+        (!a.s2w || (a.s2C0 % 16 == 0 && a.s2C1 % 16 == 0))))
+    return false;
+  const int hreal = std::min(a.bz + 2, a.Zo) * std::min(a.by + 2, a.Yo) * std::min(a.bx + 2, a.Xo);
+  const int hv = (a.bz + 2) * (a.by + 2) * (a.bx + 2);
+  return 4 * hreal <= 10 * 64 * nw && (size_t)(hv + 8) * 96 <= 160 * 1024;
+}
+
+// column blocks per workgroup (fragment packing): one -- two spill the 2-row-block form's registers
+int conv_b6d_nb(int Co) { (void)Co; return 1; }
+
+// statistics slots per sample of a launch with this geometry
+int conv_b6d_slots(const ConvArgs &a, int nw, int mbw) { return (a.Zo / a.bz) * (a.Yo / a.by) * (a.Xo / a.bx) * nw * mbw; }
+
+hipError_t launch_conv_b6d(const ConvArgs &a_in, int nw, int mbw, hipStream_t st) {
+  ConvArgs a = a_in;
+  a.dbg = conv_dbg_flags();
+  if (!conv_b6d_ok(a, nw, mbw)) return hipErrorInvalidValue;
+  B6dTabs tb;
+  hipError_t et = b6d_tabs_get(a, nw, mbw, &tb);
+  if (et != hipSuccess) return et;
+  const int nb = conv_b6d_nb(a.Co);
+  const size_t lds = (size_t)tb.HVP * 2 * 12 * sizeof(float);
+  const dim3 grid((unsigned)(a.B * tb.ntp), (unsigned)(a.Co / (32 * nb)));
+#define CM_B6D_GO(W, M, N)                                                                          \
+  if (nw == W && mbw == M && nb == N) {                                                             \
+    static bool attr_set[64] = {false};                                                             \
+    int dev = 0;                                                                                    \
+    (void)hipGetDevice(&dev);                                                                       \
+    if (!attr_set[dev & 63]) {                                                                      \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_b6d_kernel<W, M, N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (e != hipSuccess) return e;                                                                \
+      attr_set[dev & 63] = true;                                                                    \
+    }                                                                                               \
+    hipLaunchKernelGGL((conv_b6d_kernel<W, M, N>), grid, dim3(64 * W), lds, st, a, tb.tS, tb.tM, tb.NSP, tb.HVP, tb.PY, tb.PZ, tb.ntp); \
+    return hipGetLastError();                                                                       \
+  }
+  CM_B6D_GO(2, 1, 1) CM_B6D_GO(2, 2, 1) CM_B6D_GO(4, 1, 1) CM_B6D_GO(4, 2, 1)
+#undef CM_B6D_GO
+  return hipErrorInvalidValue;
+}
+
+// Split fragments from the layer's fp32 weights in the REFERENCE layout [Co][Ci][kH][kW][kL] (taps = 27; internal tap (dz, dy, dx)
+// is reference element [dy][dx][dz], cm_model.cpp: to_internal_taps) or [Co][Ci] (taps = 1): the device-side twin of pack_b6d,
+// run after an optimizer step.  One thread per (n tile, chunk, tap, nb, lane, j); the three terms by the same RNE cascade.
+__global__ __launch_bounds__(256) void b6d_repack_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Co, int Ci,
+                                                         int taps, int NB, long long n) {
+  const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (o >= n) return;
+  const int j = (int)(o & 7), lane = (int)((o >> 3) & 63);
+  long long qd = o >> 9;
+  const int nb = (int)(qd % NB); qd /= NB;
+  const int t = (int)(qd % taps); qd /= taps;
+  const int nc = Ci / 16;
+  const int c = (int)(qd % nc);
+  const int nt = (int)(qd / nc);
+  const int co = nt * 32 * NB + nb * 32 + (lane & 31), ci = 16 * c + 8 * (lane >> 5) + j;
+  const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+  const int tref = taps == 27 ? (dy * 3 + dx) * 3 + dz : 0;
+  float rem = co < Co ? w[((size_t)co * Ci + ci) * taps + tref] : 0.f;
+  const size_t base = ((((((size_t)nt * nc + c) * taps + t) * NB + nb) * 3) * 64 + lane) * 8 + j;
+#pragma unroll
+  for (int tm = 0; tm < 3; ++tm) {
+    const __bf16 h = (__bf16)rem;
+    out[base + (size_t)tm * 64 * 8] = __builtin_bit_cast(unsigned short, h);
+    rem -= (float)h;
+  }
+}
+
+hipError_t launch_b6d_repack(const float *w, float *w6, int Co, int Ci, int taps, int NB, hipStream_t st) {
+  const long long n = (long long)(Co / (32 * NB)) * (Ci / 16) * taps * NB * 64 * 8;
+  hipLaunchKernelGGL(b6d_repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, reinterpret_cast<unsigned short *>(w6), Co, Ci,
+                     taps, NB, n);
+  return hipGetLastError();
+}
+
+}  // namespace cm

@@ -121,6 +121,9 @@ struct Op {
   float *d_wups_b6 = nullptr;   // fp32 plan, inference forward: bf16 x 3 split fragments (pack_ups_b6) for the six-term products
   long long wups_b6_stride = 0;
   float *d_w16d = nullptr, *d_w16d_skip = nullptr;
+  bool b6d = false;         // fp32 plan: direct six-term kernel (cm_conv_b6d.hip) instead of the six-term Winograd one (inference forward)
+  int b6d_bz = 0, b6d_by = 0, b6d_bx = 0, b6d_nw = 0, b6d_mbw = 0;
+  float *d_wb6d = nullptr, *d_wb6d_skip = nullptr;
   bool qr = false;          // whole-sample kernel of the lowest resolution (cm_conv_qr.hip), inference plan
   float *d_wqr = nullptr, *d_wqr_skip = nullptr;
   float *d_wqr_b6 = nullptr;    // exact bf16 x 3 split of d_wqr for the six-term form of conv_qr2 (pack_qr_b6)
@@ -799,6 +802,29 @@ std::vector<float> pack_f16d(const float *w, int Co, int Ci, int taps, int NB) {
   return packed;
 }
 
+// bf16 x 3 fragments of the direct six-term kernel (cm_conv_b6d.hip): [Co/(32 NB)][Ci/16][taps][NB][term hi / mid / lo][lane][8 bf16]
+// with co = 32 NB nt + 32 nb + lane % 32, ci = 16 c + 8 (lane / 32) + j; `w` is [Co][Ci][taps] (taps = 27 internal order, or 1).
+// The device re-derives them from the reference-layout master weights after an optimizer step (b6d_repack_kernel).
+std::vector<float> pack_b6d(const float *w, int Co, int Ci, int taps, int NB) {
+  const int ntn = Co / (32 * NB), nc = Ci / 16;
+  std::vector<uint16_t> out((size_t)ntn * nc * taps * NB * 3 * 64 * 8, 0);
+  for (int nt = 0; nt < ntn; ++nt)
+    for (int c = 0; c < nc; ++c)
+      for (int t = 0; t < taps; ++t)
+        for (int nb = 0; nb < NB; ++nb)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int co = nt * 32 * NB + nb * 32 + (lane & 31), ci = 16 * c + 8 * (lane >> 5) + j;
+              uint16_t t3[3];
+              bf16_split3(w[((size_t)co * Ci + ci) * taps + t], t3);
+              for (int tm = 0; tm < 3; ++tm)
+                out[(((((((size_t)nt * nc + c) * taps + t) * NB + nb) * 3 + tm) * 64) + lane) * 8 + j] = t3[tm];
+            }
+  std::vector<float> packed(out.size() / 2);
+  std::memcpy(packed.data(), out.data(), out.size() * 2);
+  return packed;
+}
+
 // Weights of the whole-sample quarter-resolution kernel (cm_conv_qr.hip): [Co/32][g = k8*9 + dy*3 + dx][dz][lane][jj]
 // with co = 32 nt + lane % 32, ci = 8 k8 + 4 (lane / 32) + jj; `wi` in the internal tap order [Co][Ci][(dz*3 + dy)*3 + dx].
 std::vector<float> pack_qr(const std::vector<float> &wi, int Co, int Ci) {
@@ -851,6 +877,19 @@ std::vector<float> pack_qr_skip(const float *w2, int Co, int Cs) {
         for (int jj = 0; jj < 4; ++jj, ++o)
           out[o] = w2[(size_t)(nt * 32 + (lane & 31)) * Cs + 8 * gs + 4 * (lane >> 5) + jj];
   return out;
+}
+
+// Which Winograd-eligible layers take the direct six-term kernel instead.  Round 4, same-box A/B on the full-resolution layers
+// (B = 64, ATC): 82 / 84 / 208 / 109 / 142 / 99 us against the six-term Winograd kernel's 55 / 62 / 144 / 76 / 98 / 67 (step 1.563
+// vs 1.381 ms) -- its phases add up (skeleton 23 + matrix 50 + epilogue 10 us on the 32 -> 32 layer), see DESIGN section 6 --
+// so NONE by default; CM_B6D=full (Co = 32, >= 8 planes) / all under CM_DIAG=1 select it for A/B runs and the parity tests.
+bool b6d_wanted(int Co, int Z, int Y, int X) {
+  (void)Y; (void)X;
+  if (const char *e = cm::diag_env("CM_B6D")) {
+    if (!strcmp(e, "all")) return true;
+    if (!strcmp(e, "full")) return Co == 32 && Z >= 8;
+  }
+  return false;
 }
 
 int add_conv(cm_model *m, const ConvSpec &s) {
@@ -999,6 +1038,14 @@ int add_conv(cm_model *m, const ConvSpec &s) {
       if (upload(m, pack_f16d(wi.data(), s.Co, Ci_ref, 27, s.Co % 64 == 0 ? 2 : 1), &op.d_w16d)) return 1;
       op.f16d = true;
     }
+    // fp32 plan, full-resolution layers (Co = 32: one output tile, so the Winograd form has no second tile to share its U image with):
+    // the direct six-term kernel -- the split paid once per staged element instead of once per frequency component, 1.5 instead of
+    // 8 vector instructions per matrix instruction (cm_conv_b6d.hip)
+    if (m->precision != CM_PRECISION_F16 && Ci_ref == Ci_pad && a.C0 % 16 == 0 && a.C1 % 16 == 0 && b6d_wanted(s.Co, s.out->Z, s.out->Y, s.out->X) &&
+        cm::conv_b6d_pick(s.out->Z, s.out->Y, s.out->X, &op.b6d_bz, &op.b6d_by, &op.b6d_bx, &op.b6d_nw, &op.b6d_mbw)) {
+      if (upload(m, pack_b6d(wi.data(), s.Co, Ci_ref, 27, cm::conv_b6d_nb(s.Co)), &op.d_wb6d)) return 1;
+      op.b6d = true;
+    }
   }
   // the UNet's first conv (C <= 8 data channels -> base): dedicated kernel, whole weight set in registers
   if (s.s0 == m->x8_act && s.ntaps == 27 && s.stride == 1 && !s.ups && !s.gn && !s.temb && !s.resid && !s.s1 &&
@@ -1070,6 +1117,15 @@ int add_conv(cm_model *m, const ConvSpec &s) {
       if (upload(m, pack_f16d(w2.host.data(), s.Co, Cs, 1, s.Co % 64 == 0 ? 2 : 1), &op.d_w16d_skip)) return 1;
     } else {
       op.f16d = false;
+    }
+  }
+  if (op.b6d && op.d_s2w) {
+    const Param &w2 = P(m, s.skip_w);
+    const int Cs = (int)w2.shape[1];
+    if (Cs % 16 == 0 && s.skip0->C % 16 == 0 && (!s.skip1 || s.skip1->C % 16 == 0)) {
+      if (upload(m, pack_b6d(w2.host.data(), s.Co, Cs, 1, cm::conv_b6d_nb(s.Co)), &op.d_wb6d_skip)) return 1;
+    } else {
+      op.b6d = false;
     }
   }
   // Lowest resolution (two z planes, <= 64 voxels per plane): whole-sample kernel with the GroupNorm finalisation of its
@@ -1523,6 +1579,20 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
       op.stat_act->nslots = ns16;
     }
     CM_HIP(cm::launch_conv_f16d(ca, op.f16d_mbw, st));
+  } else if (op.wino && op.b6d && !m->train_fwd && m->precision != CM_PRECISION_F16) {
+    // fp32 plan, inference forward: direct six-term kernel with its own tile geometry / statistics slots
+    ca.bz = op.b6d_bz; ca.by = op.b6d_by; ca.bx = op.b6d_bx;
+    ca.wfrag = op.d_wb6d;
+    if (ca.s2w) ca.s2w = op.d_wb6d_skip;
+    if (op.stat_act) {
+      const int ns6 = cm::conv_b6d_slots(ca, op.b6d_nw, op.b6d_mbw);
+      if (ns6 > MAX_SLOTS) return fail("statistics slots %d exceed %d", ns6, MAX_SLOTS);
+      ca.stat_ns = ns6;
+      ca.stat_part = op.stat_act->part + (size_t)b0 * ns6 * ca.stat_C * 2;
+      ca.stat_cnt = op.stat_act->cnt + (size_t)b0 * ns6;
+      op.stat_act->nslots = ns6;
+    }
+    CM_HIP(cm::launch_conv_b6d(ca, op.b6d_nw, op.b6d_mbw, st));
   } else if (op.wino) {
     // reduced-precision plan: f16 operands in the inference forward; the training forward stays fp32
     const bool f16 = op.d_wwino16 && !m->train_fwd;
@@ -2556,6 +2626,10 @@ static int exec_flops_split(const cm_model *m, int32_t B, double flops[8], doubl
       const double tiles = (double)(a.Zo / op.f16d_bz) * (a.Yo / op.f16d_by) * (a.Xo / op.f16d_bx);
       f = tiles * 128.0 * op.f16d_mbw * a.Co * (Ci * 27.0 + (op.d_w16d_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
       mult16 = 1.0;
+    } else if (op.b6d && !p16) {
+      const double tiles = (double)(a.Zo / op.b6d_bz) * (a.Yo / op.b6d_by) * (a.Xo / op.b6d_bx);
+      f = tiles * 32.0 * op.b6d_nw * op.b6d_mbw * a.Co * (Ci * 27.0 + (op.d_wb6d_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
+      mult16 = 6.0;
     } else if (op.qr) {
       if (op.d_wqr_b6 && 8 * (a.Yo + 2) * (a.Xo + 2) <= 64 * 9) mult16 = 6.0;   // (conv_qr2_b6_ok)
       const double rows = 2.0 * (a.Yo * a.Xo > 32 ? 2 : 1) * 32;        // whole 32-row blocks, one or two per plane
