@@ -1661,6 +1661,14 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
       CM_HIP(hipEventCreate(&e1));
       CM_HIP(hipEventRecord(e0, st));
     }
+    {
+      static const bool sync_ops = cm::diag_env("CM_SYNC_OPS") != nullptr;   // debugging: name every op and drain the device before it
+      if (sync_ops) {
+        const hipError_t e = hipDeviceSynchronize();
+        fprintf(stderr, "[cm] forward reaches op %zu %s (%s)\n", oi, op.label.c_str(), hipGetErrorString(e));
+        fflush(stderr);
+      }
+    }
     // a K-split layer's second pass can carry the GroupNorm finalisation of the op that consumes its output
     tl_fin_next = nullptr; tl_fin_done = false;
     size_t fin_at = 0;

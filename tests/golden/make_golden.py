@@ -17,6 +17,7 @@ What is captured:
   loop_grids.npz    (--only loop_grids) _generate_ddpm T=50 on the HERMES-CR-120 (28x24) and 2x ATC (24x72) grids,
                     _generate_ddim divider 50 on CR-120
   train_full_cr120.npz  (--only train_grids) full-width training step on the CR-120 grid
+  fwd_geoms.npz     (--only fwd_geoms) the reference UNet's forward on the ETH-UCY 8x12 and ATC_medium (16 frames, base 64) geometries
   energy.npz        (--only energy) models/guidance.py compute_energy on synthetic sequences
   motion_feat.npz   (--only motion_feat) utils/metrics/motionFeatureExtractor.py vectors + MF_MSE / MF_BHATT tables
 
@@ -198,6 +199,27 @@ def gen_fwd(out):
             d[f"{gname}_c{C}/out"] = y.numpy()
             print("fwd", gname, C, float(y.abs().max()))
     np.savez_compressed(os.path.join(out, "fwd.npz"), **d)
+
+
+# the reference's own forward on two of its OTHER shipped geometries (round-3 verdict item 5): ETH-UCY 8x12
+# (config/ETHUCY_ddpm.yml:9-10,26-27,38-43) and ATC_medium 12x36 with 8 + 8 frames, BASE_CH 64 (config/ATC_medium.yml:9-10,26-27,38-43)
+GEOMS = {"ethucy": (8, 12, 5, 3, 32, (False, False, True, False), 3),
+         "atc_medium": (12, 36, 8, 8, 64, (False, False, True), 4)}
+
+
+def gen_fwd_geoms(out):
+    d = {}
+    for name, (H, W, P, F, base, att, C) in GEOMS.items():
+        cfg = spec.UNetConfig(C, C, 1, base, (1, 2, 4), att, 0.1, 4, "Past")
+        net = ref_unet(cfg, spec.init_params(cfg, SEED_W))
+        past, fut = synth_inputs(2, C, H, W, P, F, f"geom/{name}")
+        t = np.array([999, 17], dtype=np.int64)
+        with torch.inference_mode():
+            y = net(torch.from_numpy(fut), torch.from_numpy(t), torch.from_numpy(past))
+        d[f"{name}/t"] = t
+        d[f"{name}/out"] = y.numpy()
+        print("fwd_geoms", name, y.shape, float(y.abs().max()))
+    np.savez_compressed(os.path.join(out, "fwd_geoms.npz"), **d)
 
 
 def loop_noise(tag, B, per, t):
@@ -576,6 +598,8 @@ def main():
         gen_ops(a.out)
     if "fwd" in todo:
         gen_fwd(a.out)
+    if "fwd_geoms" in todo:
+        gen_fwd_geoms(a.out)
     if "train" in todo:
         gen_train(a.out)
     if "train_full" in todo:

@@ -100,6 +100,21 @@ def test_full_forward_torch_oracle(key):
     assert err <= 1e-5, err
 
 
+@pytest.mark.parametrize("name", ["ethucy", "atc_medium"])
+def test_forward_torch_oracle_on_other_shipped_geometries(name):
+    """ETH-UCY 8x12 and ATC_medium (16 frames, base 64): the oracle against the reference's own forward (fwd_geoms.npz) --
+    the pin behind tests/test_gpu_ref_geometries.py."""
+    g = load("fwd_geoms.npz")
+    H, W, P_, F, base, att, C = {"ethucy": (8, 12, 5, 3, 32, (False, False, True, False), 3),
+                                 "atc_medium": (12, 36, 8, 8, 64, (False, False, True), 4)}[name]
+    cfg = spec.UNetConfig(C, C, 1, base, (1, 2, 4), att, 0.1, 4, "Past")
+    past, fut = synth_inputs(2, C, H, W, P_, F, f"geom/{name}")
+    y = ot.unet_forward(ot.to_torch(spec.init_params(cfg, SEED_W)), spec.make_plan(cfg), torch.from_numpy(fut),
+                        torch.from_numpy(g[f"{name}/t"]), torch.from_numpy(past))
+    err = np.abs(y.numpy() - g[f"{name}/out"]).max()
+    assert err <= 1e-5, err
+
+
 def test_full_forward_numpy_oracle_atc():
     g = load("fwd.npz")
     cfg = full_cfg(3)
