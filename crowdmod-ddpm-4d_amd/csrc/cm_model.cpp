@@ -121,6 +121,7 @@ struct Op {
   float *d_wups_b6 = nullptr;   // fp32 plan, inference forward: bf16 x 3 split fragments (pack_ups_b6) for the six-term products
   long long wups_b6_stride = 0;
   float *d_w16d = nullptr, *d_w16d_skip = nullptr;
+  bool dbg_raw = false;     // cm_debug_conv_io: the whole-sample quarter-resolution kernel without its GroupNorm (raw sources)
   bool b6d = false;         // fp32 plan: direct six-term kernel (cm_conv_b6d.hip) instead of the six-term Winograd one (inference forward)
   int b6d_bz = 0, b6d_by = 0, b6d_bx = 0, b6d_nw = 0, b6d_mbw = 0;
   float *d_wb6d = nullptr, *d_wb6d_skip = nullptr;
@@ -1416,6 +1417,7 @@ int run_conv_qr(cm_model *m, Op &op, int B, hipStream_t st, int b0) {
   if (g1) { q.part1 = g1->part + (size_t)b0 * g1->nslots * g1->C * 2; q.cnt1 = g1->cnt + (size_t)b0 * g1->nslots; q.ns1 = g1->nslots; }
   if (g0->C != ca.C0 || (g1 ? g1->C : 0) != ca.C1) return fail("quarter-resolution conv %s: statistics and sources disagree", op.label.c_str());
   q.gamma = gop.gamma; q.beta = gop.beta; q.groups = GN_GROUPS; q.eps = GN_EPS; q.silu = ca.silu;
+  if (op.dbg_raw) { q.gamma = q.beta = nullptr; q.raw = 1; q.silu = 0; }
   q.wq = op.d_wqr; q.bias = ca.bias;
   q.wq6 = op.d_wqr_b6;
   q.temb = ca.temb; q.temb_stride = ca.temb_stride; q.tidx = ca.tidx + b0;
@@ -2547,6 +2549,37 @@ int cm_debug_conv_info(const cm_model *m, int32_t index, char *buf, int64_t capa
   snprintf(buf, (size_t)capacity, "conv %s %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d", op.label.c_str(), a.ntaps, a.stride, a.par,
            a.C0 + a.C1, a.Co, a.Zo, a.Yo, a.Xo, op.NB, op.MB, a.bz, a.by, a.bx, op.ks,
            (op.small_n ? 1 : 0) | (op.first_k ? 2 : 0) | (op.stat_act ? 4 : 0) | (op.skip_if_fused ? 8 : 0) | (a.CK == 32 ? 16 : 0));
+  return 0;
+}
+
+// Test hook (tests/test_gpu_six_term_hostile.py): conv op `index` ALONE on the caller's data -- no GroupNorm / SiLU on load, no
+// time-embedding row, no residual, no fused skip conv; the bias stays.  h_in0 / h_in1: host, channels-last
+// [B][Zs][Ys][Xs][C0 / C1] (h_in1 null when the op has one source); h_out: host [B][Zo][Yo][Xo][channel stride of the output
+// tensor].  mode 0: the kernel the plan runs (six-term bf16 products where the plan has them); mode 1: the same layer on fp32
+// matrix instructions (the split fragments withheld).
+int cm_debug_conv_io(cm_model *m, int32_t index, int32_t mode, const float *h_in0, const float *h_in1, float *h_out, int32_t B) {
+  if (check_ready(m, B)) return 1;
+  if (!h_in0 || !h_out || index < 0 || index >= (int)m->ops.size()) return fail("bad argument");
+  Op &op = m->ops[index];
+  if (op.kind != OP_CONV || !op.in0 || !op.out_act) return fail("op %d is not a convolution", index);
+  if (op.tuned_B < 0 && !op.qr) return fail("run a forward first");
+  if ((op.in1 != nullptr) != (h_in1 != nullptr)) return fail("op %d has %d source tensors", index, op.in1 ? 2 : 1);
+  DevGuard g(m->device);
+  hipStream_t st = m->stream;
+  const size_t Vs = (size_t)op.in0->V(), Vo = (size_t)op.out_act->V();
+  CM_HIP(hipMemcpy(op.in0->d, h_in0, (size_t)B * Vs * op.in0->C * sizeof(float), hipMemcpyHostToDevice));
+  if (op.in1) CM_HIP(hipMemcpy(op.in1->d, h_in1, (size_t)B * Vs * op.in1->C * sizeof(float), hipMemcpyHostToDevice));
+  Op tmp = op;
+  tmp.ca.gn = nullptr; tmp.ca.silu = 0; tmp.ca.temb = nullptr; tmp.temb_off = -1; tmp.ca.resid = nullptr; tmp.resid_act = nullptr;
+  tmp.d_s2w = nullptr; tmp.d_wqr_skip = nullptr; tmp.skip_if_fused = false; tmp.dbg_raw = true; tmp.pm_off = -1;
+  if (mode == 1) { tmp.d_wwino_b6 = nullptr; tmp.d_wqr_b6 = nullptr; tmp.d_wups_b6 = nullptr; tmp.b6d = false; }
+  const int ns_keep = op.stat_act ? op.stat_act->nslots : 0;
+  const int rc = run_conv(m, tmp, B, st, 0, 0);
+  const hipError_t e = hipStreamSynchronize(st);
+  if (op.stat_act) op.stat_act->nslots = ns_keep;
+  if (rc) return 1;
+  if (e != hipSuccess) return fail("debug conv launch failed: %s", hipGetErrorString(e));
+  CM_HIP(hipMemcpy(h_out, op.out_act->d, (size_t)B * Vo * op.out_act->C * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -96,6 +96,7 @@ SIGNATURES = {
     "cm_debug_conv_flags": (C.c_int, [C.c_int32]),
     "cm_debug_conv_count": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "cm_debug_conv_info": (C.c_int, [_P, C.c_int32, C.c_char_p, C.c_int64]),
+    "cm_debug_conv_io": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32]),
     "cm_debug_time_conv": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.POINTER(C.c_float)]),
     "cm_train_init": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),

@@ -232,6 +232,10 @@ int cm_frame_metrics(int32_t device, const float *d_pred, const float *d_gt, int
 int cm_debug_conv_flags(int32_t flags);
 int cm_debug_conv_count(const cm_model *m, int32_t *count);
 int cm_debug_conv_info(const cm_model *m, int32_t index, char *buf, int64_t capacity);
+/* Test hook: conv op `index` alone on caller data (no GroupNorm / SiLU / time row / residual / fused skip; bias stays).
+ * h_in0 / h_in1: host channels-last [B][Zs][Ys][Xs][C0 / C1]; h_out: host [B][Zo][Yo][Xo][C of the output tensor];
+ * mode 0 = the plan's kernel, 1 = the same layer on fp32 matrix instructions (six-term fragments withheld). */
+int cm_debug_conv_io(cm_model *m, int32_t index, int32_t mode, const float *h_in0, const float *h_in1, float *h_out, int32_t B);
 int cm_debug_time_conv(cm_model *m, int32_t index, int32_t MB, int32_t bz, int32_t by, int32_t bx,
                        int32_t B, int32_t iters, float *us);
 
