@@ -607,7 +607,13 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
   const int quad = it & 3, patch = (it >> 2) % NP, zi = it / (4 * NP);
   const bool stager = itid < NITEMS && !(CMP && (zi == 0 || zi == HZ - 1));   // CMP: padding planes are never transformed
   const int urow = zi * NP + patch;
-  float *const uw = U + (size_t)urow * S + ((F16 || B6) ? 2 : 4) * (SWZ ? (quad ^ ((urow >> 2) & 3)) : quad);
+  // CMP (compact six-term image): a component is [k half hh][row][term][4 dwords] -- row stride 12 dwords, the three terms of a
+  // lane's fragment at immediate offsets 0 / 16 / 32 bytes: the 16 rows of a ds_read_b128 service group sit on 16 different
+  // 16-byte bank groups (12 r mod 64 = 4 (3 r mod 16)); the term-major row of 24 dwords it replaces put rows r and r + 8 on the
+  // same banks (2-way conflicts on every A fragment: the 0.45 conflict share of round 3)
+  float *const uw = CMP ? U + (size_t)((quad >> 1) * URC + urow) * 12 + 2 * (quad & 1)
+                        : U + (size_t)urow * S + ((F16 || B6) ? 2 : 4) * (SWZ ? (quad ^ ((urow >> 2) & 3)) : quad);
+  constexpr int TST = CMP ? 4 : 8;                 // dwords between the terms of a row
   const int rbase = (((zi - (CMP ? 1 : 0)) * RYH + 2 * (patch / PX)) * RXH + 2 * (patch % PX)) * RS_ + 4 * quad;
 
   const int n0 = a.C0 >> 4, nchunks = n0 + (a.C1 >> 4);
@@ -633,11 +639,13 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
   }
 
   const int ar = min(r, ROWS - 1);
-  const float *arow = U + (size_t)(wave * 4) * URC * S + (size_t)ar * S + (SWZ ? 0 : 4 * hh);
+  const float *arow = CMP ? U + (size_t)(wave * 4) * URC * S + (size_t)(hh * URC + ar) * 12
+                          : U + (size_t)(wave * 4) * URC * S + (size_t)ar * S + (SWZ ? 0 : 4 * hh);
   // CMP: row block of halo plane z + dz; plane HZ - 1 (top padding) is the zero block 0
-  int rowoff[3] = {0, NP * S, 2 * NP * S};
+  constexpr int RST = CMP ? 12 : S;                // dwords between consecutive rows of a lane's k half
+  int rowoff[3] = {0, NP * RST, 2 * NP * RST};
   if constexpr (CMP) {
-    if (ar / NP == BZ - 1) rowoff[2] = -(ar / NP) * NP * S;   // z = 7, dz = 2: block 0 instead of block 9
+    if (ar / NP == BZ - 1) rowoff[2] = -(ar / NP) * NP * RST;   // z = 7, dz = 2: block 0 instead of block 9
   }
   // this lane's output rows of the epilogue: reg -> row (reg & 3) + 8 (reg >> 2) + 4 hh of sub-block `wave`
   // (read once per workgroup after the table has landed, below)
@@ -720,10 +728,10 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
       }
       __syncthreads();                          // R complete; every wave is past the previous matrix phase / exchange reads
       if constexpr (CMP) {
-        if (ch == 0)                              // the zero block (the previous tile's exchange overwrote it)
-          for (int i = tid; i < 16 * NP * (S / 4); i += NT) {
-            const int xi = i / (NP * (S / 4)), rem = i - xi * (NP * (S / 4));
-            *reinterpret_cast<f32x4 *>(U + (size_t)xi * URC * S + 4 * rem) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ch == 0)                              // the zero block (the previous tile's exchange overwrote it): rows [0, NP) of both k halves
+          for (int i = tid; i < 16 * 2 * NP * 3; i += NT) {
+            const int xi = i / (2 * NP * 3), rem = i - xi * (2 * NP * 3), hf2 = rem / (NP * 3), r4 = rem - hf2 * (NP * 3);
+            *reinterpret_cast<f32x4 *>(U + (size_t)xi * URC * S + (size_t)hf2 * URC * 12 + 4 * r4) = f32x4{0.f, 0.f, 0.f, 0.f};
           }
       }
       // ---- step B: B^T d B of the item's 4x4 patch out of R ------------------------------------------------
@@ -738,7 +746,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
             cm_u32x2_t t3[3];
             cm_split3_bf16(v, t3);                  // hi / mid / lo planes, exact remainders
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<cm_u32x2_t *>(uw + (size_t)k * URC * S + 8 * tm) = t3[tm];
+            for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<cm_u32x2_t *>(uw + (size_t)k * URC * S + TST * tm) = t3[tm];
           } else if constexpr (F16) {
             const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             *reinterpret_cast<f16x4 *>(uw + (size_t)k * URC * S) = hv;
@@ -794,7 +802,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
         const float *ab = arow;                    // (F16-style fragment: 8 halves per lane at 4 hh dwords, planes 8 dwords apart)
         f32x4 af6[2][3];
 #pragma unroll
-        for (int tm = 0; tm < 3; ++tm) af6[0][tm] = *reinterpret_cast<const f32x4 *>(ab + rowoff[0] + 8 * tm);
+        for (int tm = 0; tm < 3; ++tm) af6[0][tm] = *reinterpret_cast<const f32x4 *>(ab + rowoff[0] + TST * tm);
 #pragma unroll
         for (int sx = 0; sx < 12; ++sx) {          // step = (z tap g, component x)
           const int g = sx >> 2, x = sx & 3;
@@ -803,7 +811,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
             const int g1 = (sx + 1) >> 2, x1 = (sx + 1) & 3;
 #pragma unroll
             for (int tm = 0; tm < 3; ++tm)
-              af6[(sx + 1) & 1][tm] = *reinterpret_cast<const f32x4 *>(ab + (size_t)x1 * URC * S + rowoff[g1] + 8 * tm);
+              af6[(sx + 1) & 1][tm] = *reinterpret_cast<const f32x4 *>(ab + (size_t)x1 * URC * S + rowoff[g1] + TST * tm);
           }
           // (A term, B term), small products first: hi = 0, mid = 1, lo = 2
           constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};

@@ -268,6 +268,41 @@ void test_round3_packers() {
     a.ntaps = 27; a.stride = 1; a.C0 = 32; a.Co = 32; a.Zs = a.Zo = g[0]; a.Ys = a.Yo = g[1]; a.Xs = a.Xo = g[2]; a.bz = bz; a.by = by; a.bx = bx;
     EXPECT(cm::conv_f16d_ok(a, mbw) && cm::conv_f16d_slots(a, mbw) <= MAX_SLOTS);
   }
+  // direct six-term kernel (cm_conv_b6d.hip): tile picker, staging lists and row tables on the full-resolution grids of the
+  // reference configs -- every real halo voxel staged exactly once into its own LDS row, every output voxel owned by exactly one
+  // row, tap reads inside the image, and a row order whose ds_read_b128 service groups are conflict-free
+  {
+    const int fgrids[][3] = {{8, 12, 36}, {8, 28, 24}, {8, 24, 72}, {16, 12, 36}, {8, 8, 12}, {8, 12, 20}, {4, 6, 18}};
+    for (auto &g : fgrids) {
+      int bz = 0, by = 0, bx = 0, nw = 0, mbw = 0;
+      EXPECT(cm::conv_b6d_pick(g[0], g[1], g[2], &bz, &by, &bx, &nw, &mbw));
+      cm::ConvArgs a{};
+      a.ntaps = 27; a.stride = 1; a.C0 = 32; a.Co = 32; a.Zs = a.Zo = g[0]; a.Ys = a.Yo = g[1]; a.Xs = a.Xo = g[2]; a.bz = bz; a.by = by; a.bx = bx;
+      EXPECT(cm::conv_b6d_ok(a, nw, mbw) && cm::conv_b6d_slots(a, nw, mbw) <= MAX_SLOTS);
+      std::vector<int> tS, tM;
+      int NSP = 0, HVP = 0, PY = 0, PZ = 0, ntp = 0, conf = -1;
+      cm::conv_b6d_tables(g[0], g[1], g[2], bz, by, bx, nw, mbw, tS, tM, &NSP, &HVP, &PY, &PZ, &ntp, &conf);
+      const int HV = (bz + 2) * (by + 2) * (bx + 2), MR = 32 * nw * mbw, V = g[0] * g[1] * g[2];
+      EXPECT(ntp == (g[0] / bz) * (g[1] / by) * (g[2] / bx) && HVP >= HV && (HVP & 7) == 4 && 4 * NSP <= 10 * 64 * nw);
+      if (g[0] == 8 && g[1] % 4 == 0 && g[2] % 4 == 0) EXPECT(conf == 0);
+      std::vector<int> owned((size_t)V, 0);
+      for (int p = 0; p < ntp; ++p) {
+        std::vector<char> rowseen((size_t)HV, 0);
+        for (int i = 0; i < NSP; ++i) {
+          const int src = tS[((size_t)p * NSP + i) * 2], row = tS[((size_t)p * NSP + i) * 2 + 1];
+          if (src < 0) continue;
+          EXPECT(src < V && row >= 0 && row < HV && !rowseen[(size_t)row]);
+          rowseen[(size_t)row] = 1;
+        }
+        for (int m2 = 0; m2 < MR; ++m2) {
+          const int hidx = tM[((size_t)p * MR + m2) * 2], ov = tM[((size_t)p * MR + m2) * 2 + 1];
+          EXPECT(hidx >= 0 && hidx + 2 * PZ + 2 * PY + 2 < HVP);
+          if (ov >= 0) { EXPECT(ov < V); owned[(size_t)ov] += 1; EXPECT(rowseen[(size_t)(hidx + PZ + PY + 1)]); }   // its centre tap is a staged voxel
+        }
+      }
+      for (int v = 0; v < V; ++v) EXPECT(owned[(size_t)v] == 1);
+    }
+  }
   // stage-once upsample kernel: a source tile for every upsample source grid of the reference configs (ATC, CR-120, 24x72),
   // planes tiles where a plane fits one row block; the launcher's own feasibility test agrees with the picker
   const int srcs[][3] = {{2, 3, 9}, {4, 6, 18}, {2, 7, 6}, {4, 14, 12}, {2, 6, 18}, {4, 12, 36}};

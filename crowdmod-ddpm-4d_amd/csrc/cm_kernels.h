@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <vector>
 
 namespace cm {
 
@@ -225,6 +226,9 @@ bool conv_b6d_ok(const ConvArgs &a, int nw, int mbw);
 int conv_b6d_slots(const ConvArgs &a, int nw, int mbw);
 int conv_b6d_nb(int Co);
 hipError_t launch_conv_b6d(const ConvArgs &a, int nw, int mbw, hipStream_t st);
+// host-side geometry tables of one (grid, tile) pair (cm_conv_b6d.hip; also driven by the sanitizer self-test)
+void conv_b6d_tables(int Z, int Y, int X, int bz, int by, int bx, int nw, int mbw, std::vector<int> &tS, std::vector<int> &tM,
+                     int *NSP, int *HVP, int *PY, int *PZ, int *ntp, int *conflicts);
 // split fragments from the layer's fp32 weights in the REFERENCE layout [Co][Ci][kH][kW][kL] (or [Co][Ci], taps = 1), e.g. after an optimizer step
 hipError_t launch_b6d_repack(const float *w, float *w6, int Co, int Ci, int taps, int NB, hipStream_t st);
 

@@ -2376,20 +2376,49 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
     // streams fill independently (one thread alternating between the streams is launch-bandwidth bound).
     for (int ln = 0; ln < lanes; ++ln)
       if (lane_steps(ln, 0, 1)) return 1;
+    // (nothing may throw across the C ABI: a worker's exception becomes its lane's error; a lane whose thread cannot be
+    //  created is enqueued from the calling thread instead)
     std::vector<int> rcs((size_t)lanes, 0);
     std::vector<std::string> errs((size_t)lanes);
     std::vector<std::thread> workers;
-    for (int ln = 1; ln < lanes; ++ln)
-      workers.emplace_back([&, ln]() {
-        if (hipSetDevice(m->device) != hipSuccess) { rcs[ln] = 1; errs[ln] = "hipSetDevice failed in a lane thread"; return; }
-        rcs[ln] = lane_steps(ln, 1, order.size());
-        if (rcs[ln]) errs[ln] = g_err;
-      });
-    rcs[0] = lane_steps(0, 1, order.size());
-    if (rcs[0]) errs[0] = g_err;
+    std::vector<char> started((size_t)lanes, 0);
+    try {
+      workers.reserve((size_t)lanes);
+      for (int ln = 1; ln < lanes; ++ln) {
+        try {
+          workers.emplace_back([&, ln]() {
+            try {
+              if (hipSetDevice(m->device) != hipSuccess) { rcs[ln] = 1; errs[ln] = "hipSetDevice failed in a lane thread"; return; }
+              rcs[ln] = lane_steps(ln, 1, order.size());
+              if (rcs[ln]) errs[ln] = g_err;
+            } catch (const std::exception &e) {
+              rcs[ln] = 1;
+              try { errs[ln] = e.what(); } catch (...) {}
+            } catch (...) {
+              rcs[ln] = 1;
+            }
+          });
+          started[ln] = 1;
+        } catch (...) {
+          started[ln] = 0;                        // no thread for this lane: the calling thread enqueues it below
+        }
+      }
+      rcs[0] = lane_steps(0, 1, order.size());
+      if (rcs[0]) errs[0] = g_err;
+      for (int ln = 1; ln < lanes; ++ln)
+        if (!started[ln]) {
+          rcs[ln] = lane_steps(ln, 1, order.size());
+          if (rcs[ln]) errs[ln] = g_err;
+        }
+    } catch (const std::exception &e) {
+      rcs[0] = 1;
+      try { errs[0] = e.what(); } catch (...) {}
+    } catch (...) {
+      rcs[0] = 1;
+    }
     for (auto &w : workers) w.join();
     for (int ln = 0; ln < lanes; ++ln)
-      if (rcs[ln]) return fail("lane %d: %s", ln, errs[ln].c_str());
+      if (rcs[ln]) return fail("lane %d: %s", ln, errs[ln].empty() ? "exception in the lane's enqueue thread" : errs[ln].c_str());
   }
   for (int ln = 1; ln < lanes; ++ln) {
     CM_HIP(hipEventRecord(m->ev_join[ln], sts[ln]));
@@ -2672,7 +2701,13 @@ static int exec_flops_split(const cm_model *m, int32_t B, double flops[8], doubl
       f = tiles * 32.0 * op.b6d_nw * op.b6d_mbw * a.Co * (Ci * 27.0 + (op.d_wb6d_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
       mult16 = 6.0;
     } else if (op.qr) {
-      if (op.d_wqr_b6 && 8 * (a.Yo + 2) * (a.Xo + 2) <= 64 * 9) mult16 = 6.0;   // (conv_qr2_b6_ok)
+      {
+        // the launcher's own predicate (conv_qr2_b6_ok: 8 groups, channel bound, LDS fit), not a copy of one of its clauses
+        cm::QrArgs q{};
+        q.C0 = a.C0; q.C1 = a.C1; q.Co = a.Co; q.Y = a.Yo; q.X = a.Xo; q.groups = GN_GROUPS; q.raw = 1; q.wq6 = op.d_wqr_b6;
+        if (op.d_wqr_skip) { q.s2w = op.d_wqr_skip; q.s2C0 = op.skip0->C; q.s2C1 = op.skip1 ? op.skip1->C : 0; }
+        if (op.d_wqr_b6 && cm::conv_qr2_b6_ok(q)) mult16 = 6.0;
+      }
       const double rows = 2.0 * (a.Yo * a.Xo > 32 ? 2 : 1) * 32;        // whole 32-row blocks, one or two per plane
       f = rows * a.Co * (Ci * 18.0 + (op.d_wqr_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
     } else if (op.wino) {

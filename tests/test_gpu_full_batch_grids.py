@@ -292,3 +292,30 @@ def test_six_term_bf16_products_agree_with_the_fp32_matrix_instructions(tmp_path
         assert np.isfinite(a).all() and a.shape == b.shape
         assert not np.array_equal(a, b), "the switches did not change the kernels"
         assert float(np.abs(a - b).max()) <= 1e-5 * max(1.0, float(np.abs(b).max())), gname
+
+
+def test_direct_six_term_kernel_agrees_with_the_six_term_winograd_kernel(tmp_path):
+    """cm_conv_b6d.hip (round 4: the six-term products in DIRECT form on the full-resolution layers -- split once per staged
+    element, no Winograd transforms; opt-in, CM_DIAG=1 CM_B6D=full, because it measured slower than the Winograd form) against
+    the default plan: whole-denoiser forwards at B = 8 on all three reference grids, fused skip convs included.  Same exact
+    products, different summation (27 taps direct vs 16 frequency components), so agreement is to fp32 rounding and not bit
+    for bit."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    res = {}
+    for tag, extra in (("wino", {}), ("direct", {"CM_DIAG": "1", "CM_B6D": "full"})):
+        path = str(tmp_path / f"{tag}.npz")
+        env = dict(os.environ, **extra)
+        env.pop("CM_CONV_DBG", None)
+        r = subprocess.run([sys.executable, "-c", _UPS_CHILD.format(root=root, tests=here, path=path)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(path)
+    for gname in ("atc", "cr120", "atc2x"):
+        a, b = res["direct"][gname], res["wino"][gname]
+        assert np.isfinite(a).all() and a.shape == b.shape
+        assert not np.array_equal(a, b), "the switch did not change the kernel"
+        assert float(np.abs(a - b).max()) <= 1e-5 * max(1.0, float(np.abs(b).max())), gname

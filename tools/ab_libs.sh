@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 for rep in $(seq 1 ${REPS:-2}); do
   for lib in "$@"; do
     if [ $lib = cur ]; then unset CM_LIB_PATH; else export CM_LIB_PATH=$GRAFT_REPO_ROOT/$lib; fi
-    v=$(python bench.py --steps ${STEPS:-100} --warmup 10 --cpu-budget 0 --no-profile $BENCH_FLAGS 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
+    v=$(python bench.py --steps ${STEPS:-100} --warmup 10 --cpu-budget 0 --no-profile --no-secondary $BENCH_FLAGS 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
     echo "[$lib] $v"
   done
 done

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; cd $R
 for tag in remap noremap; do
   mkdir -p gpurun_out/prof_fetch_$tag
   if [ $tag = noremap ]; then export CM_DIAG=1 CM_CONV_DBG=4096; else unset CM_CONV_DBG; fi
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch_$tag -- python bench.py --steps 2 --warmup 0 --no-profile --cpu-budget 0 > gpurun_out/prof_fetch_$tag.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch_$tag -- python bench.py --lanes 1 --no-secondary --steps 2 --warmup 0 --no-profile --cpu-budget 0 > gpurun_out/prof_fetch_$tag.log 2>&1
 done
 python - <<'PY'
 import csv, glob, os, re

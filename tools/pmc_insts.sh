@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_insts
 mkdir -p $OUT
 cd $R
-CM_LANES=1 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_INSTS_SMEM --output-format csv -d $OUT/a -- python bench.py --steps 2 --warmup 0 --no-profile --cpu-budget 0 > $OUT/a.log 2>&1
+CM_LANES=1 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_INSTS_SMEM --output-format csv -d $OUT/a -- python bench.py --lanes 1 --no-secondary --steps 2 --warmup 0 --no-profile --cpu-budget 0 > $OUT/a.log 2>&1
 python - <<'PY'
 import csv, glob, collections, os
 f = glob.glob(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out/prof_insts/a/*/*_counter_collection.csv"))[0]

@@ -12,13 +12,13 @@ OUT=$R/gpurun_out/prof_${1:-r1}
 mkdir -p $OUT
 cd $R
 STEPS=${STEPS:-10}
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --lanes 1 --steps $STEPS --warmup 2 --repeats 1 --no-profile --cpu-budget 0 > $OUT/trace.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_lanes2 -- python bench.py --steps $STEPS --warmup 2 --repeats 1 --no-profile --cpu-budget 0 > $OUT/trace_lanes2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python bench.py --lanes 1 --steps 2 --warmup 0 --repeats 1 --no-profile --cpu-budget 0 > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python bench.py --lanes 1 --steps 2 --warmup 0 --repeats 1 --no-profile --cpu-budget 0 > $OUT/write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python bench.py --lanes 1 --steps 2 --warmup 0 --repeats 1 --no-profile --cpu-budget 0 > $OUT/sq.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --lanes 1 --steps $STEPS --warmup 2 --repeats 1 --no-profile --no-secondary --cpu-budget 0 > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_lanes2 -- python bench.py --steps $STEPS --warmup 2 --repeats 1 --no-profile --no-secondary --cpu-budget 0 > $OUT/trace_lanes2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python bench.py --lanes 1 --steps 2 --warmup 0 --repeats 1 --no-profile --no-secondary --cpu-budget 0 > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python bench.py --lanes 1 --steps 2 --warmup 0 --repeats 1 --no-profile --no-secondary --cpu-budget 0 > $OUT/write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python bench.py --lanes 1 --steps 2 --warmup 0 --repeats 1 --no-profile --no-secondary --cpu-budget 0 > $OUT/sq.log 2>&1
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-python bench.py --lanes 1 --cpu-budget 0 > $OUT/bench_lanes1.json 2>> $OUT/bench.err
+python bench.py --lanes 1 --no-secondary --cpu-budget 0 > $OUT/bench_lanes1.json 2>> $OUT/bench.err
 python bench.py --mode train > $OUT/bench_train.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python bench.py --mode train --steps 5 --warmup 2 --repeats 1 > $OUT/trace_train.log 2>&1
 python bench.py --dtype f16 --config config/ATC_synthetic.yml --batch 32 --cpu-budget 0 > $OUT/bench_f16_24x72.json 2>> $OUT/bench.err
