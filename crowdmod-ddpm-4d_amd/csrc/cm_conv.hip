@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg)
             if (nok && offs[reg] >= 0) outp[(size_t)offs[reg] * a.out_cs + n] = rs[reg];
-          if (a.stat_part && !(a.dbg & 256)) {
+          if ((a.stat_part || a.astat) && !(a.dbg & 256)) {
             // fused GroupNorm statistics of this 32-row block (two-pass on registers, the
             // two lane halves merged with one cross-lane exchange): layers.py:30,41 read them
             float s1 = 0.f, cnt = 0.f;
@@ -722,12 +722,16 @@ __global__ __launch_bounds__(256, (OCC ? OCC : (BZ != 0 && MB * NB <= 4 ? CM_SPE
               if (offs[reg] >= 0) { const float d = rs[reg] - mean; q += d * d; }
             q += __shfl_xor(q, 32);
             const int slot = ((par * a.ntz + tz) * a.nty + ty) * a.ntx * MB + tx * MB + mb;
-            if (h == 0 && nok && b0 < a.B) {
-              float *sp = a.stat_part + (((size_t)b0 * a.stat_ns + slot) * a.stat_C + n) * 2;
-              sp[0] = mean;
-              sp[1] = q;
+            if (a.astat) {                          // accumulator statistics (no gn_finalize launch): exact integer adds
+              if (h == 0 && nok && b0 < a.B && cnt > 0.f) cm_stat_atomic(a.astat + ((size_t)b0 * a.astat_C + n) * 3, s1, mean, q);
+            } else {
+              if (h == 0 && nok && b0 < a.B) {
+                float *sp = a.stat_part + (((size_t)b0 * a.stat_ns + slot) * a.stat_C + n) * 2;
+                sp[0] = mean;
+                sp[1] = q;
+              }
+              if (lane == 0 && n == 0 && b0 < a.B) a.stat_cnt[(size_t)b0 * a.stat_ns + slot] = cnt;
             }
-            if (lane == 0 && n == 0 && b0 < a.B) a.stat_cnt[(size_t)b0 * a.stat_ns + slot] = cnt;
           }
         }
       }
@@ -911,7 +915,7 @@ __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const ConvArgs a, long
 }
 
 bool conv1x1_f16_ok(const ConvArgs &a, int NB) {
-  return a.ntaps == 1 && a.td == 1 && a.stride == 1 && !a.par && !a.ups && !(a.C0 & 15) && !(a.C1 & 15) && !a.stat_part && a.ks <= 1 &&
+  return a.ntaps == 1 && a.td == 1 && a.stride == 1 && !a.par && !a.ups && !(a.C0 & 15) && !(a.C1 & 15) && !a.stat_part && !a.astat && a.ks <= 1 &&
          !a.temb && !a.s2w && (NB == 1 || NB == 2) && a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo;
 }
 
@@ -926,7 +930,7 @@ hipError_t launch_conv1x1_f16(const ConvArgs &a, int NB, hipStream_t st) {
 }
 
 bool conv1x1_flat_ok(const ConvArgs &a, int NB) {
-  return a.ntaps == 1 && a.td == 1 && a.stride == 1 && !a.par && !a.ups && a.CK == 32 && !(a.C0 & 31) && !(a.C1 & 31) && !a.stat_part &&
+  return a.ntaps == 1 && a.td == 1 && a.stride == 1 && !a.par && !a.ups && a.CK == 32 && !(a.C0 & 31) && !(a.C1 & 31) && !a.stat_part && !a.astat &&
          a.ks <= 1 && !a.temb && !a.s2w && !a.f16 && (NB == 1 || NB == 2) && a.Zs == a.Zo && a.Ys == a.Yo && a.Xs == a.Xo &&
          !(conv_dbg_flags() & 65536);
 }

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b6d_kernel(const ConvArgs a, 
 #pragma unroll
       for (int e = 0; e < 16; ++e)
         if (nok && orow[e] >= 0) outb[(size_t)orow[e] * a.out_cs + nn] = rs[e];
-      if (a.stat_part) {
+      if (a.stat_part || a.astat) {
         float s1 = 0.f, cnt = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e)
@@ -302,12 +302,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b6d_kernel(const ConvArgs a, 
           if (orow[e] >= 0) { const float dd = rs[e] - mean; q2 += dd * dd; }
         q2 += __shfl_xor(q2, 32);
         const int slot = p * (NW * MBW) + wave * MBW + j;
-        if (hh == 0 && nok) {
-          float *sp2 = a.stat_part + (((size_t)b * ns + slot) * a.stat_C + nn) * 2;
-          sp2[0] = mean;
-          sp2[1] = q2;
+        if (a.astat) {
+          if (hh == 0 && nok && cnt > 0.f) cm_stat_atomic(a.astat + ((size_t)b * a.astat_C + nn) * 3, s1, mean, q2);
+        } else {
+          if (hh == 0 && nok) {
+            float *sp2 = a.stat_part + (((size_t)b * ns + slot) * a.stat_C + nn) * 2;
+            sp2[0] = mean;
+            sp2[1] = q2;
+          }
+          if (lane == 0 && nn == 0) a.stat_cnt[(size_t)b * ns + slot] = cnt;
         }
-        if (lane == 0 && nn == 0) a.stat_cnt[(size_t)b * ns + slot] = cnt;
       }
     }
   }

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvArgs a, const
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg)
       if (nok && offs[reg] >= 0) a.out[(size_t)offs[reg] * a.out_cs + n] = rs[reg];
-    if (a.stat_part) {
+    if (a.stat_part || a.astat) {
       // GroupNorm statistics of the block (two-pass on registers; the two lane halves hold disjoint rows)
       float s1 = 0.f, cnt = 0.f;
 #pragma unroll
@@ -149,12 +149,16 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvArgs a, const
         if (offs[reg] >= 0) { const float d = rs[reg] - mean; q += d * d; }
       q += __shfl_xor(q, 32);
       const int slot = (tz * a.nty + ty) * nblk + blk;
-      if (hh == 0 && nok && b < a.B) {
-        float *sp = a.stat_part + (((size_t)b * a.stat_ns + slot) * a.stat_C + n) * 2;
-        sp[0] = mean;
-        sp[1] = q;
+      if (a.astat) {
+        if (hh == 0 && nok && b < a.B && cnt > 0.f) cm_stat_atomic(a.astat + ((size_t)b * a.astat_C + n) * 3, s1, mean, q);
+      } else {
+        if (hh == 0 && nok && b < a.B) {
+          float *sp = a.stat_part + (((size_t)b * a.stat_ns + slot) * a.stat_C + n) * 2;
+          sp[0] = mean;
+          sp[1] = q;
+        }
+        if (lane == 0 && n == 0 && b < a.B) a.stat_cnt[(size_t)b * a.stat_ns + slot] = cnt;
       }
-      if (lane == 0 && n == 0 && b < a.B) a.stat_cnt[(size_t)b * a.stat_ns + slot] = cnt;
     }
   }
 }

@@ -84,7 +84,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const f32x16 &v
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg)
     if (nok && offs[reg] >= 0) a.out[(size_t)offs[reg] * a.out_cs + n] = rs[reg];
-  if (a.stat_part) {
+  if (a.stat_part || a.astat) {
     float s1 = 0.f, cnt = 0.f;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg)
@@ -97,12 +97,16 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const f32x16 &v
     for (int reg = 0; reg < 16; ++reg)
       if (offs[reg] >= 0) { const float dd = rs[reg] - mean; q += dd * dd; }
     q += __shfl_xor(q, 32);
-    if (hh == 0 && nok && b0 < a.B) {
-      float *sp2 = a.stat_part + (((size_t)b0 * a.stat_ns + slot) * a.stat_C + n) * 2;
-      sp2[0] = mean;
-      sp2[1] = q;
+    if (a.astat) {
+      if (hh == 0 && nok && b0 < a.B && cnt > 0.f) cm_stat_atomic(a.astat + ((size_t)b0 * a.astat_C + n) * 3, s1, mean, q);
+    } else {
+      if (hh == 0 && nok && b0 < a.B) {
+        float *sp2 = a.stat_part + (((size_t)b0 * a.stat_ns + slot) * a.stat_C + n) * 2;
+        sp2[0] = mean;
+        sp2[1] = q;
+      }
+      if (lane == 0 && n == 0 && b0 < a.B) a.stat_cnt[(size_t)b0 * a.stat_ns + slot] = cnt;
     }
-    if (lane == 0 && n == 0 && b0 < a.B) a.stat_cnt[(size_t)b0 * a.stat_ns + slot] = cnt;
   }
 }
 
@@ -567,6 +571,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
   int *outoff = reinterpret_cast<int *>(lds);       // [4 sub-blocks (a, b)][32 rows] in-sample output voxel index or -1
   float *U = lds + 128;
   float *R = U + UX;
+  float *GNL = R + RVC * RS_;                       // accumulator statistics (a.gs0): scale / shift rows [2][C0 + C1] of the current sample
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -687,9 +692,17 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
   const int n2a = SKIP ? a.s2C0 >> 5 : 0, n2 = SKIP ? (a.s2C0 + a.s2C1) >> 5 : 0;
   const int slot = p * 4 + wave;
 
+  const bool norm = a.gn != nullptr || a.gs0 != nullptr;     // GroupNorm (+ SiLU) on load
   for (int b = g0; b < a.B; b += G) {
     const bool more_b = b + G < a.B;
     const float tv_pre = a.temb ? a.temb[(size_t)a.tidx[b] * a.temb_stride + nc_epi] : 0.f;
+    if (a.gs0) {
+      // the GroupNorm of this sample's input finalised HERE from the producers' accumulators (no gn_finalize launch): the halo
+      // loads of the first chunk are already in flight, the rows are read from LDS in step A
+      __syncthreads();                            // (the previous sample's last step A has read its rows, its epilogue the exchange buffer)
+      cm_gn_rows_from_sums(a, b, (int)Vs, GNL, reinterpret_cast<double *>(U), tid, NT);   // (U is free here: scratch)
+      __syncthreads();
+    }
     f32x16 acc[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
@@ -698,11 +711,16 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
 
     for (int ch = 0; ch < nchunks; ++ch) {
       // ---- step A: this chunk's halo voxels -> activated image R ------------------------------------------
-      const f32x4 sc1 = scn, sh1 = shn;
+      f32x4 sc1 = scn, sh1 = shn;
+      if (a.gs0) {
+        const int cb0 = (ch < n0 ? ch * CS : a.C0 + (ch - n0) * CS) + 4 * aq;
+        sc1 = *reinterpret_cast<const f32x4 *>(GNL + cb0);
+        sh1 = *reinterpret_cast<const f32x4 *>(GNL + Ctot + cb0);
+      }
       f32x4 pm1 = {1.f, 1.f, 1.f, 1.f};
       if (!((CM_WINO_ABL & 32) && ch > 0)) {
       if (a.pm) pm1 = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + (ch < n0 ? ch * CS : a.C0 + (ch - n0) * CS) + 4 * aq);
-      if (a.gn && a.silu && !a.pm) {
+      if (norm && a.silu && !a.pm) {
 #pragma unroll
         for (int k = 0; k < RK; ++k) {
           const int v = (tid >> 2) + (NT / 4) * k + RV0;
@@ -716,7 +734,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
         for (int k = 0; k < RK; ++k) {
           const int v = (tid >> 2) + (NT / 4) * k + RV0;
           f32x4 w = ald[k];
-          if (a.gn) {
+          if (norm) {
             w = w * sc1 + sh1;
             if (a.silu) { w[0] = silu_w(w[0]); w[1] = silu_w(w[1]); w[2] = silu_w(w[2]); w[3] = silu_w(w[3]); }
           }
@@ -947,7 +965,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
           if (nok && orow[reg] >= 0)
             *reinterpret_cast<float *>(reinterpret_cast<char *>(outb) + (__umul24((unsigned)orow[reg], ocs4) + n4)) = rs[reg];
       }
-      if (a.stat_part) {
+      if (a.stat_part || a.astat) {
         float s1 = 0.f, cnt = 0.f;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
@@ -960,12 +978,16 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
         for (int reg = 0; reg < 16; ++reg)
           if (orow[reg] >= 0) { const float dd = rs[reg] - mean; q += dd * dd; }
         q += __shfl_xor(q, 32);
-        if (hh == 0 && nok) {
-          float *sp2 = a.stat_part + (((size_t)b * a.stat_ns + slot) * a.stat_C + n) * 2;
-          sp2[0] = mean;
-          sp2[1] = q;
+        if (a.astat) {
+          if (hh == 0 && nok && cnt > 0.f) cm_stat_atomic(a.astat + ((size_t)b * a.astat_C + n) * 3, s1, mean, q);
+        } else {
+          if (hh == 0 && nok) {
+            float *sp2 = a.stat_part + (((size_t)b * a.stat_ns + slot) * a.stat_C + n) * 2;
+            sp2[0] = mean;
+            sp2[1] = q;
+          }
+          if (lane == 0 && n == 0) a.stat_cnt[(size_t)b * a.stat_ns + slot] = cnt;
         }
-        if (lane == 0 && n == 0) a.stat_cnt[(size_t)b * a.stat_ns + slot] = cnt;
       }
     }
   }
@@ -1172,7 +1194,7 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
   // sample lanes balance worse (85 vs 79 us).  CM_WINO_P=1 under CM_DIAG forces it everywhere for A/B runs.
   static const bool all_p = cm::diag_env("CM_WINO_P") != nullptr;
   if (conv_wino_two_step(a.bz, a.by, a.bx, f16, nbw) && !no_p && (nbw == 2 || all_p || b6)) {
-    const size_t ldsp = conv_wino_p_lds(a.bz, a.by, a.bx, f16, nbw, b6);
+    const size_t ldsp = conv_wino_p_lds(a.bz, a.by, a.bx, f16, nbw, b6) + (a.gs0 ? (size_t)2 * (a.C0 + a.C1) * sizeof(float) : 0);
     const int ntp = a.ntz * a.nty * a.ntx, nz = (a.Co + 31) / 32 / nbw;
     const int per_cu = (nbw == 1 && 2 * ldsp <= 160 * 1024) ? 2 : 1;
     const int slots = wino_cu_count() * per_cu;

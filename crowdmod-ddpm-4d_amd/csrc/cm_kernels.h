@@ -106,7 +106,82 @@ struct ConvArgs {
   int f16;             // 1: wfrag holds f16 fragments (4 halves per lane and step); specialised parity form only
   int zsplit;          // weight gradient of a 27-tap layer on a two-plane grid: mtab rows [0,32) are plane 0, [32,64) plane 1,
                        //   and a row block skips the z tap that multiplies its padding plane (18 of 27 taps, as the forward)
+  // Round 4 -- GroupNorm statistics WITHOUT the gn_finalize launch (inference plan).  Producer side: instead of slot partials,
+  // every 32-row block ADDS its per-channel sums to astat[b][astat_C][3] (64-bit fixed point: sum x * 2^16 as two's complement,
+  // floor(sum x^2 / 2^32), (sum x^2 mod 2^32) * 2^20): integer adds are exact and order-independent, so the totals are
+  // bit-identical however the launch is tiled, sharded or scheduled -- cm_stat_atomic.  Consumer side: the workgroup finalises
+  // the GroupNorm of its input itself from the accumulators of its (one or two) source tensors -- cm_gn_rows_from_sums.
+  unsigned long long *astat;             // output accumulator rows of sample 0 of this launch, or null (then stat_part as before)
+  int astat_C;                           //   accumulator channels per sample (row stride in channels)
+  const unsigned long long *gs0, *gs1;   // consumer: accumulators of src0 / src1, [B][gs_C][3] from sample 0 of this launch (null: a.gn rows)
+  int gs_C;
+  const float *gs_gamma, *gs_beta;       //   affine of this layer's GroupNorm over the C0 + C1 input channels
+  int gs_groups;
+  float gs_eps;
 };
+#ifdef __HIPCC__
+// ---- statistics accumulators (ConvArgs::astat) ----------------------------------------------------------------------------
+constexpr unsigned long long CM_STAT_POISON = 1ull << 63;      // a non-finite or out-of-range contribution was added
+// One 32-row block's contribution for one channel: s1 = sum of its rows, mean = s1 / cnt, m2 = sum (x - mean)^2 (all fp32, as
+// the slot format holds them).  sum x^2 = m2 + s1 * mean is formed in fp64, so the fixed-point words lose nothing the fp32
+// partials had.  Range: |sum x| < 2^46 and sum x^2 < 2^94 per sample and channel; beyond that (or NaN / Inf) the poison bit is set
+// and the consumer's statistics come out NaN, as non-finite slot partials did.
+__device__ __forceinline__ void cm_stat_atomic(unsigned long long *acc, float s1, float mean, float m2) {
+  const double q = (double)m2 + (double)s1 * (double)mean;
+  const double sx = (double)s1 * 65536.0;
+  if (!(fabs(sx) < 4.0e18) || !(q < 1.9e28)) {                 // (also catches NaN)
+    __hip_atomic_fetch_or(acc + 1, CM_STAT_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const double qh = floor(q * (1.0 / 4294967296.0));
+  const unsigned long long QH = (unsigned long long)qh;
+  const unsigned long long QL = (unsigned long long)((q - qh * 4294967296.0) * 1048576.0 + 0.5);
+  const long long SX = __double2ll_rn(sx);
+  __hip_atomic_fetch_add(acc, (unsigned long long)SX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(acc + 1, QH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(acc + 2, QL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (sum x, sum x^2) of one channel from its accumulator words; NaN when poisoned
+__device__ __forceinline__ void cm_stat_read(const unsigned long long *acc, double *sx, double *sq) {
+  const unsigned long long w0 = acc[0], w1 = acc[1], w2 = acc[2];
+  if (w1 & CM_STAT_POISON) { *sx = __builtin_nan(""); *sq = __builtin_nan(""); return; }
+  *sx = (double)(long long)w0 * (1.0 / 65536.0);
+  *sq = (double)w1 * 4294967296.0 + (double)w2 * (1.0 / 1048576.0);
+}
+// Consumer prologue: scale / shift rows of sample `b` for the C0 + C1 input channels into rows[2 (C0 + C1)] (LDS or global):
+// rows[c] = gamma[c] * rstd(group of c), rows[Ctot + c] = beta[c] - mean * rows[c]   (nn.GroupNorm, layers.py:30,41: biased
+// variance, eps inside the root).  Called by ALL `nth` threads of the workgroup (it contains one barrier): pass 1 -- thread c
+// reads its channel's three words (ONE round trip for the whole workgroup; a loop over the group's channels per thread paid one
+// per channel, 6 us per workgroup) into `scratch` [Ctot][2] doubles in LDS; pass 2 -- every channel sums its group's entries
+// (4 ... 24 LDS reads) and finishes in registers.  V = voxels per sample.  The caller synchronises before it reads `rows`.
+__device__ __forceinline__ void cm_gn_rows_from_sums(const ConvArgs &a, int b, int V, float *rows, double *scratch, int tid, int nth) {
+  const int Ctot = a.C0 + a.C1, cg = Ctot / a.gs_groups;
+  for (int c = tid; c < Ctot; c += nth) {
+    const unsigned long long *p = c < a.C0 ? a.gs0 + ((size_t)b * a.gs_C + c) * 3 : a.gs1 + ((size_t)b * a.gs_C + (c - a.C0)) * 3;
+    const unsigned long long w0 = p[0], w1 = p[1], w2 = p[2];
+    const bool bad = (w1 & CM_STAT_POISON) != 0ull;
+    const double sx = (double)(long long)w0 * (1.0 / 65536.0);
+    const double sq = (double)w1 * 4294967296.0 + (double)w2 * (1.0 / 1048576.0);
+    scratch[2 * c] = bad ? __builtin_nan("") : sx;
+    scratch[2 * c + 1] = bad ? __builtin_nan("") : sq;
+  }
+  __syncthreads();
+  const double inv_n = 1.0 / ((double)cg * (double)V);
+  for (int c = tid; c < Ctot; c += nth) {
+    const int g0 = (c / cg) * cg;
+    double sx = 0.0, sq = 0.0;
+    for (int k = g0; k < g0 + cg; ++k) { sx += scratch[2 * k]; sq += scratch[2 * k + 1]; }
+    const double mean = sx * inv_n;
+    double var = sq * inv_n - mean * mean;
+    var = var < 0.0 ? 0.0 : var;                   // (NaN stays NaN)
+    const float rstd = 1.0f / sqrtf((float)var + a.gs_eps);
+    const float sc = a.gs_gamma[c] * rstd;
+    rows[c] = sc;
+    rows[Ctot + c] = a.gs_beta[c] - (float)mean * sc;
+  }
+}
+#endif
+
 bool conv_zsplit_variant(const ConvArgs &a, int MB, int NB);
 // does launch_conv have an f16-operand instantiation for this parity-form tile?
 bool conv_par_f16_variant(int MB, int NB, int bz, int by, int bx);
@@ -235,6 +310,10 @@ hipError_t launch_b6d_repack(const float *w, float *w6, int Co, int Ci, int taps
 // ---- small kernels --------------------------------------------------------
 // Per-(sample, slice, channel) mean and M2 of a channels-last tensor.
 //   part [B][nslice][C][2]
+// Fall-backs of the accumulator scheme (round 4): gn rows [B][2][C0 + C1] from the accumulators (a consumer kernel that cannot
+// finalise them itself), and accumulators from slot partials (a producer kernel that cannot add to them itself)
+hipError_t launch_gn_from_sums(const ConvArgs &a, int V, float *gn_rows, hipStream_t st);
+hipError_t launch_slots_to_sums(const float *part, const float *cnt, int nslots, int C, int B, unsigned long long *astat, int astat_C, hipStream_t st);
 hipError_t launch_chan_stats(const float *x, int B, int V, int C, int nslice, float *part, float *cnt, hipStream_t st);
 // Combine partial statistics (per slot: mean, M2 in part[b][slot][C][2], row count in
 // cnt[b][slot]) of (up to) two concatenated tensors into GroupNorm scale/shift rows:
@@ -314,6 +393,8 @@ struct StepArgs {
   long long boff;        // b0 * per
   // plain loop: this step also writes the NEXT step's time index into the UNet's t buffer (saves a launch per step)
   long long *t_next; long long t_next_v;
+  // round 4: this step's denoiser has consumed the GroupNorm accumulators (ConvArgs::astat); clear this lane's rows for the next step
+  unsigned long long *zero_u64; long long zero_n;
 };
 hipError_t launch_sampler_step(const StepArgs &a, hipStream_t st);
 hipError_t launch_q_sample(const float *x0, const long long *t, const float *eps, const float *sab, const float *s1m,

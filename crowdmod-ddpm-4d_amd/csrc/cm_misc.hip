@@ -933,6 +933,8 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(StepArgs a) {
   const long long total = per * a.B;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (a.t_next && i < a.B) a.t_next[i] = a.t_next_v;   // (the UNet of this step has consumed the buffer)
+  if (a.zero_u64)
+    for (long long z = i; z < a.zero_n; z += (long long)gridDim.x * 256) a.zero_u64[z] = 0ull;
   if (i >= total) return;
   const long long b = i / per, e = i - b * per;
   const int f = (int)(e % a.F);
@@ -1073,6 +1075,34 @@ hipError_t launch_count_nonfinite(const float *x, long long n, int *count, hipSt
 
 hipError_t launch_fill_t(long long *t, int B, long long value, hipStream_t st) {
   hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, st, t, B, value);
+  return hipGetLastError();
+}
+
+// ---- fall-backs of the accumulator statistics (ConvArgs::astat / gs0) ------------------------------------------------------
+// gn rows [B][2][C0 + C1] from the accumulators: for a consumer kernel that cannot finalise them in its own prologue
+__global__ __launch_bounds__(256) void gn_from_sums_kernel(const ConvArgs a, int V, float *__restrict__ rows) {
+  extern __shared__ __attribute__((aligned(16))) double gsum[];   // [C0 + C1][2]
+  const int b = blockIdx.x;
+  cm_gn_rows_from_sums(a, b, V, rows + (size_t)b * 2 * (a.C0 + a.C1), gsum, threadIdx.x, 256);
+}
+hipError_t launch_gn_from_sums(const ConvArgs &a, int V, float *gn_rows, hipStream_t st) {
+  hipLaunchKernelGGL(gn_from_sums_kernel, dim3((unsigned)a.B), dim3(256), (size_t)(a.C0 + a.C1) * 2 * sizeof(double), st, a, V, gn_rows);
+  return hipGetLastError();
+}
+// accumulators from slot partials: for a producer kernel that wrote (mean, M2, count) slots instead of adding to them
+__global__ __launch_bounds__(256) void slots_to_sums_kernel(const float *__restrict__ part, const float *__restrict__ cnt, int nslots, int C,
+                                                            unsigned long long *__restrict__ astat, int astat_C) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256)
+    for (int s2 = 0; s2 < nslots; ++s2) {
+      const float n = cnt[(size_t)b * nslots + s2];
+      if (!(n > 0.f)) continue;
+      const float *sp = part + (((size_t)b * nslots + s2) * C + c) * 2;
+      cm_stat_atomic(astat + ((size_t)b * astat_C + c) * 3, sp[0] * n, sp[0], sp[1]);
+    }
+}
+hipError_t launch_slots_to_sums(const float *part, const float *cnt, int nslots, int C, int B, unsigned long long *astat, int astat_C, hipStream_t st) {
+  hipLaunchKernelGGL(slots_to_sums_kernel, dim3((unsigned)B), dim3(256), 0, st, part, cnt, nslots, C, astat, astat_C);
   return hipGetLastError();
 }
 

@@ -72,6 +72,8 @@ struct Act {
   float *cnt = nullptr;   // [B][nslots] rows behind each slot
   int nslice = 1;         // slots when the stand-alone statistics kernel fills them
   int nslots = 0;         // slots of the last producer (fused conv epilogue or stats kernel)
+  int aoff = -1;          // >= 0: GroupNorm statistics of this tensor go to the accumulator rows (cm_model::astat_all, channel offset aoff)
+                          //   in the inference plan -- producers add exact fixed-point sums, consumers finalise, no gn_finalize launch
   int V() const { return Z * Y * X; }
 };
 
@@ -131,6 +133,7 @@ struct Op {
   bool train_qr = false;        // the training forward may take conv_qr2 as well (set by train_setup once the geometry is checked)
   long long wqr_floats = 0;
   bool qr_consumer = false; // OP_GNFIN whose only consumer is a qr conv: that kernel finalises the statistics itself
+  bool atomic = false;      // OP_GNFIN (inference plan): its source tensors keep accumulator statistics and its consumers finalise them -- no launch
   bool first_k = false;     // the UNet's first conv on its dedicated kernel (cm_conv_io.hip)
   int first_cin = 4;        //   input channels it contracts per tap: 4 (C <= 4) or 8
   float *d_wfirst = nullptr;
@@ -215,6 +218,9 @@ struct cm_model {
   long long *train_iota = nullptr;
   bool use_train_temb = false;
   float *mse_partial = nullptr, *mse_loss = nullptr;
+  unsigned long long *astat_all = nullptr;  // accumulator statistics [max_batch][astat_C][3] (ConvArgs::astat), sample-major
+  int astat_C = 0;              //   channels of all accumulator tensors together
+  struct { int b0 = -1, B = 0; } astat_clean[4];   // per batch lane: the sample range whose rows are known to be zero (the last sampler step cleared them)
   float *ks_scratch = nullptr;  // raw partial outputs of K-split convs [S][B][V][Co]
   size_t ks_scratch_floats = 0;
   float *xstate = nullptr;      // sampler state [B,C,H,W,F]
@@ -1363,6 +1369,65 @@ int build_ops(cm_model *m) {
 }
 
 // Time-embedding tables for all 1000 rows (embeddings.py:24-30 + layers.py:35,62).
+// Which GroupNorm finalisations of the INFERENCE plan can go without their launch (round 4): the source tensors' producers add
+// exact fixed-point sums to accumulator rows (cm_stat_atomic), the consuming conv finalises them in its prologue (six-term Winograd
+// kernel) or through a fall-back launch that costs what gn_finalize cost.  Eligible: fp32 plan; every source tensor produced by an
+// ordinary conv launch (no K split, not the whole-sample quarter-resolution kernel -- those feed slot partials to consumers that
+// merge slots); no consumer that merges slots itself (conv_qr).  A tensor takes accumulators only if ALL GroupNorms over it do.
+// MEASURED SLOWER than the gn_finalize launches it removes (round 4, same-box: 1.456 vs 1.413 ms per step; removing the 13 launches
+// outright would be worth 88 us): per full-resolution layer the 663 k 8-byte atomic adds -- 108 per accumulator word -- cost 14-17 us
+// (conv_first 26 -> 40 us, the stage-once upsample conv 86 -> 118) and the consumer prologue ~3 us, against the 6.4 us launch.
+// Opt-in only: CM_DIAG=1 CM_ASTAT=1 (kept with its parity test as the record of the experiment).
+int plan_astat(cm_model *m) {
+  if (m->precision == CM_PRECISION_F16 || !cm::diag_env("CM_ASTAT")) return 0;
+  const int nops = (int)m->ops.size();
+  std::map<const Act *, int> producer;
+  for (int i = 0; i < nops; ++i)
+    if (m->ops[i].kind == OP_CONV && m->ops[i].stat_act) producer[m->ops[i].stat_act] = i;
+  std::vector<char> cand((size_t)nops, 0);
+  auto act_ok = [&](const Act *a) {
+    auto it = producer.find(a);
+    if (it == producer.end()) return false;
+    const Op &po = m->ops[it->second];
+    return po.ks <= 1 && !po.qr && !po.skip_if_fused && a->part != nullptr;
+  };
+  for (int i = 0; i < nops; ++i) {
+    Op &g = m->ops[i];
+    if (g.kind != OP_GNFIN || g.qr_consumer || g.in_attn_block) continue;
+    bool ok = act_ok(g.g0) && (!g.g1 || act_ok(g.g1));
+    int ncons = 0;
+    for (int j = 0; j < nops && ok; ++j)
+      if (m->ops[j].kind == OP_CONV && m->ops[j].gn_op == i) { ++ncons; if (m->ops[j].qr) ok = false; }
+    cand[(size_t)i] = ok && ncons > 0;
+  }
+  for (bool changed = true; changed;) {            // a tensor keeps accumulators only if every GroupNorm over it is a candidate
+    changed = false;
+    for (int i = 0; i < nops; ++i) {
+      if (!cand[(size_t)i]) continue;
+      const Op &g = m->ops[i];
+      for (int j = 0; j < nops; ++j) {
+        const Op &h = m->ops[j];
+        if (h.kind != OP_GNFIN || cand[(size_t)j]) continue;
+        if (h.g0 == g.g0 || h.g0 == g.g1 || (h.g1 && (h.g1 == g.g0 || h.g1 == g.g1))) { cand[(size_t)i] = 0; changed = true; break; }
+      }
+    }
+  }
+  int totC = 0;
+  for (int i = 0; i < nops; ++i) {
+    if (!cand[(size_t)i]) continue;
+    Op &g = m->ops[i];
+    g.atomic = true;
+    for (const Act *a : {g.g0, g.g1})
+      if (a && a->aoff < 0) { const_cast<Act *>(a)->aoff = totC; totC += a->C; }
+  }
+  if (!totC) return 0;
+  m->astat_C = totC;
+  const size_t bytes = (size_t)m->cfg.max_batch * totC * 3 * sizeof(unsigned long long);
+  if (dev_alloc(m, (void **)&m->astat_all, bytes)) return 1;
+  CM_HIP(hipMemset(m->astat_all, 0, bytes));
+  return 0;
+}
+
 int build_time_table(cm_model *m) {
   const cm_unet_config &c = m->cfg;
   const int te = c.base_channels, tx = c.base_channels * c.time_multiple;
@@ -1533,6 +1598,41 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     ca.stat_cnt = op.stat_act->cnt + (size_t)b0 * ns;
     op.stat_act->nslots = ns;
   }
+  // ---- which kernel will run (needed up front: only some kernels speak the accumulator statistics of round 4) -------------------
+  static const bool no_train_b6 = cm::diag_env("CM_NO_TRAIN_B6") != nullptr;
+  const bool take_ups = op.ks <= 1 && op.ups && (op.d_wups16 || !(op.d_wfrag16 && !m->train_fwd));
+  const bool take_f16d = op.ks <= 1 && !take_ups && op.wino && op.f16d && !m->train_fwd;
+  const bool take_b6d = op.ks <= 1 && !take_ups && !take_f16d && op.wino && op.b6d && !m->train_fwd && m->precision != CM_PRECISION_F16;
+  const bool take_wino = op.ks <= 1 && !take_ups && !take_f16d && !take_b6d && op.wino;
+  const bool wino_f16 = take_wino && op.d_wwino16 && !m->train_fwd;     // reduced-precision plan: f16 operands in the inference forward
+  // two-tile layers / the full-resolution tile, fp32 plan: six-term bf16 products (the training forward as well: exact splits, fp32
+  // accumulate; its fragments follow every optimizer step)
+  const bool wino_b6 = take_wino && !wino_f16 && op.d_wwino_b6 && !(m->train_fwd && (no_train_b6 || m->precision == CM_PRECISION_F16)) &&
+                       cm::conv_wino_b6_ok(ca.bz, ca.by, ca.bx, ca.Co, ca.Zo);
+  // consumer side: the GroupNorm of the input comes from the producers' accumulator rows -- finalised inside the six-term
+  // Winograd kernel, or by a fall-back launch that writes the rows gn_finalize would have written
+  if (!m->train_fwd && m->astat_all && op.gn_op >= 0 && m->ops[op.gn_op].atomic && ca.gn) {
+    const Op &g = m->ops[op.gn_op];
+    ca.gs0 = m->astat_all + ((size_t)b0 * m->astat_C + g.g0->aoff) * 3;
+    ca.gs1 = g.g1 ? m->astat_all + ((size_t)b0 * m->astat_C + g.g1->aoff) * 3 : nullptr;
+    ca.gs_C = m->astat_C; ca.gs_gamma = g.gamma; ca.gs_beta = g.beta; ca.gs_groups = GN_GROUPS; ca.gs_eps = GN_EPS;
+    if (wino_b6) {
+      ca.gn = nullptr;
+    } else {
+      CM_HIP(cm::launch_gn_from_sums(ca, (int)Vs, const_cast<float *>(ca.gn), st));
+      ca.gs0 = ca.gs1 = nullptr;
+    }
+  }
+  // producer side: this launch adds its output's statistics to the accumulator rows instead of writing slot partials
+  const bool use_astat = !m->train_fwd && m->astat_all && op.stat_act && op.stat_act->aoff >= 0;
+  auto to_astat = [&]() {
+    if (!use_astat) return;
+    ca.astat = m->astat_all + ((size_t)b0 * m->astat_C + op.stat_act->aoff) * 3;
+    ca.astat_C = m->astat_C;
+    ca.stat_part = nullptr; ca.stat_cnt = nullptr;
+    m->astat_clean[slab & 3].B = 0;
+  };
+  if (use_astat && op.ks > 1) return fail("conv %s: a K-split layer cannot feed accumulator statistics", op.label.c_str());
   if (op.ks > 1) {
     cm::ConvArgs ka = ca;
     const int V = op.out_act->V();
@@ -1551,7 +1651,7 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     cb.stat_cnt = op.stat_act->cnt + (size_t)b0 * cb.nslots;
     op.stat_act->nslots = cb.nslots;
     if (run_combine(m, cb, st)) return 1;
-  } else if (op.ups && (op.d_wups16 || !(op.d_wfrag16 && !m->train_fwd))) {
+  } else if (take_ups) {
     // upsample conv: stage-once parity kernel with its own source tile / statistics slots (f16 operands under the
     // reduced-precision plan's inference forward)
     if (op.d_wups16 && !m->train_fwd) { ca.wfrag = op.d_wups16; ca.wpar_stride = op.wups16_stride; ca.f16 = 1; }
@@ -1566,8 +1666,9 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
       ca.stat_cnt = op.stat_act->cnt + (size_t)b0 * nsu;
       op.stat_act->nslots = nsu;
     }
+    to_astat();
     CM_HIP(cm::launch_conv_ups(ca, op.ups_mbw, op.ups_planes, op.NB, st));
-  } else if (op.wino && op.f16d && !m->train_fwd) {
+  } else if (take_f16d) {
     // reduced-precision plan: direct f16 kernel with its own tile geometry / statistics slots
     ca.bz = op.f16d_bz; ca.by = op.f16d_by; ca.bx = op.f16d_bx;
     ca.wfrag = op.d_w16d;
@@ -1581,7 +1682,12 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
       op.stat_act->nslots = ns16;
     }
     CM_HIP(cm::launch_conv_f16d(ca, op.f16d_mbw, st));
-  } else if (op.wino && op.b6d && !m->train_fwd && m->precision != CM_PRECISION_F16) {
+    if (use_astat) {                               // (this kernel writes slot partials only: convert them)
+      m->astat_clean[slab & 3].B = 0;
+      CM_HIP(cm::launch_slots_to_sums(ca.stat_part, ca.stat_cnt, ca.stat_ns, ca.stat_C, B,
+                                      m->astat_all + ((size_t)b0 * m->astat_C + op.stat_act->aoff) * 3, m->astat_C, st));
+    }
+  } else if (take_b6d) {
     // fp32 plan, inference forward: direct six-term kernel with its own tile geometry / statistics slots
     ca.bz = op.b6d_bz; ca.by = op.b6d_by; ca.bx = op.b6d_bx;
     ca.wfrag = op.d_wb6d;
@@ -1594,18 +1700,15 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
       ca.stat_cnt = op.stat_act->cnt + (size_t)b0 * ns6;
       op.stat_act->nslots = ns6;
     }
+    to_astat();
     CM_HIP(cm::launch_conv_b6d(ca, op.b6d_nw, op.b6d_mbw, st));
-  } else if (op.wino) {
-    // reduced-precision plan: f16 operands in the inference forward; the training forward stays fp32
-    const bool f16 = op.d_wwino16 && !m->train_fwd;
-    ca.wfrag = f16 ? op.d_wwino16 : op.d_wwino;
-    // two-tile layers, fp32 plan, inference forward: six-term bf16 products (same tile geometry as the plan picked)
-    // (the training forward as well: exact splits, fp32 accumulate; its fragments follow every optimizer step)
-    static const bool no_train_b6 = cm::diag_env("CM_NO_TRAIN_B6") != nullptr;
-    if (!f16 && op.d_wwino_b6 && !(m->train_fwd && (no_train_b6 || m->precision == CM_PRECISION_F16)) &&
-        cm::conv_wino_b6_ok(ca.bz, ca.by, ca.bx, ca.Co, ca.Zo)) { ca.wfrag = op.d_wwino_b6; ca.f16 = 2; }
-    CM_HIP(cm::launch_conv_wino(ca, f16, st));
+  } else if (take_wino) {
+    ca.wfrag = wino_f16 ? op.d_wwino16 : op.d_wwino;
+    if (wino_b6) { ca.wfrag = op.d_wwino_b6; ca.f16 = 2; }
+    to_astat();
+    CM_HIP(cm::launch_conv_wino(ca, wino_f16, st));
   } else if (op.first_k) {
+    to_astat();
     CM_HIP(cm::launch_conv_first(ca, op.first_cin, op.d_wfirst, st));
   } else if (op.small_n) {
     CM_HIP(cm::launch_conv_smalln(ca, op.MB, op.d_wsmall, st));
@@ -1618,6 +1721,7 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     if (op.d_wfrag16 && !m->train_fwd && cm::conv_par_f16_variant(op.MB, op.NB, ca.bz, ca.by, ca.bx)) {
       ca.wfrag = op.d_wfrag16; ca.wpar_stride = op.wpar_stride16; ca.f16 = 1;   // f16 operands, fp32 accumulate
     }
+    to_astat();
     CM_HIP(cm::launch_conv(ca, op.MB, op.NB, st));
   }
   return 0;
@@ -1653,6 +1757,14 @@ int run_combine(cm_model *m, cm::CombineArgs &cb, hipStream_t st) {
 // Every sample-indexed pointer is offset by b0, so two disjoint sub-batches can run
 // concurrently on two streams (`slab` selects the stream's K-split scratch region).
 int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
+  if (m->astat_all && !m->train_fwd) {
+    // accumulator statistics: this forward ADDS to the rows of its samples -- they must be zero.  The sampling loop's step
+    // kernel clears them for the next step (no launch); any other caller pays one memset here.
+    auto &cl = m->astat_clean[slab & 3];
+    if (!(cl.b0 <= b0 && b0 + B <= cl.b0 + cl.B))
+      CM_HIP(hipMemsetAsync(m->astat_all + (size_t)b0 * m->astat_C * 3, 0, (size_t)B * m->astat_C * 3 * sizeof(unsigned long long), st));
+    cl.B = 0;                                     // dirty from here on
+  }
   for (size_t oi = 0; oi < m->ops.size(); ++oi) {
     Op &op = m->ops[oi];
     // the fused attention block runs in the inference plan, its four generic ops in the training forward
@@ -1693,6 +1805,7 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
       }
       case OP_GNFIN: {
         if (op.qr_consumer && !m->train_fwd) break;   // its consumer finalises the statistics itself (cm_conv_qr.hip)
+        if (op.atomic && !m->train_fwd) break;        // accumulator statistics: finalised by the consuming conv (run_conv)
         { static const bool skip = cm::diag_env("CM_SKIP_GNFIN") != nullptr; if (skip) break; }   // timing bound only (stale rows)
         if (op.g1 && op.g1->V() != op.g0->V()) return fail("concat sources disagree on voxel count");
         const Act *g0 = op.g0, *g1 = op.g1;
@@ -2033,6 +2146,7 @@ int cm_model_finalize(cm_model *m) {
   if (dev_alloc(m, (void **)&m->tbuf, B * sizeof(long long))) return 1;
   CM_HIP(hipMemset(m->tbuf, 0, B * sizeof(long long)));
   if (build_ops(m)) return 1;
+  if (plan_astat(m)) return 1;
   if (build_time_table(m)) return 1;
   const size_t per = (size_t)m->per_sample();
   const size_t per_past = (size_t)c.in_channels * c.rows * c.cols * c.past_len;
@@ -2327,7 +2441,9 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
       al.sample_id_base = opts->sample_id_base;
       al.tab = m->d_steptab; al.kctr = m->d_kctr; al.row_stride = (long long)B * per; al.boff = 0;
       al.hist = d_history; al.noise = d_noise;
+      if (m->astat_all) { al.zero_u64 = m->astat_all; al.zero_n = (long long)B * m->astat_C * 3; }
       CM_HIP(cm::launch_sampler_step(al, st));
+      if (m->astat_all) { m->astat_clean[0].b0 = 0; m->astat_clean[0].B = B; }
       return 0;
     };
     if (enqueue_step()) return 1;
@@ -2364,7 +2480,12 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
       al.sample_id_base = opts->sample_id_base + b0;
       al.hist = d_history ? d_history + (k + 1) * B * per + (size_t)b0 * per : nullptr;
       al.noise = (d_noise && al.draw) ? d_noise + k * B * per + (size_t)b0 * per : nullptr;
+      if (m->astat_all) {                          // the step kernel clears this lane's accumulator rows for the next forward
+        al.zero_u64 = m->astat_all + (size_t)b0 * m->astat_C * 3;
+        al.zero_n = (long long)Bn * m->astat_C * 3;
+      }
       CM_HIP(cm::launch_sampler_step(al, ls));
+      if (m->astat_all) { m->astat_clean[ln & 3].b0 = b0; m->astat_clean[ln & 3].B = Bn; }
     }
     return 0;
   };
@@ -2601,6 +2722,8 @@ int cm_debug_conv_io(cm_model *m, int32_t index, int32_t mode, const float *h_in
   Op tmp = op;
   tmp.ca.gn = nullptr; tmp.ca.silu = 0; tmp.ca.temb = nullptr; tmp.temb_off = -1; tmp.ca.resid = nullptr; tmp.resid_act = nullptr;
   tmp.d_s2w = nullptr; tmp.d_wqr_skip = nullptr; tmp.skip_if_fused = false; tmp.dbg_raw = true; tmp.pm_off = -1;
+  if (!tmp.qr) tmp.gn_op = -1;
+  if (tmp.stat_act && tmp.stat_act->aoff >= 0) tmp.stat_act = nullptr;      // (no additions to the accumulator rows of the plan)
   if (mode == 1) { tmp.d_wwino_b6 = nullptr; tmp.d_wqr_b6 = nullptr; tmp.d_wups_b6 = nullptr; tmp.b6d = false; }
   const int ns_keep = op.stat_act ? op.stat_act->nslots : 0;
   const int rc = run_conv(m, tmp, B, st, 0, 0);

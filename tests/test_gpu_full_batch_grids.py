@@ -319,3 +319,30 @@ def test_direct_six_term_kernel_agrees_with_the_six_term_winograd_kernel(tmp_pat
         assert np.isfinite(a).all() and a.shape == b.shape
         assert not np.array_equal(a, b), "the switch did not change the kernel"
         assert float(np.abs(a - b).max()) <= 1e-5 * max(1.0, float(np.abs(b).max())), gname
+
+
+def test_accumulator_statistics_agree_with_the_gn_finalize_launches(tmp_path):
+    """Round-4 experiment kept opt-in (CM_DIAG=1 CM_ASTAT=1): GroupNorm statistics as exact fixed-point atomic sums added by the
+    producing convs and finalised in the consuming Winograd kernel's prologue -- no gn_finalize launch -- against the default plan
+    (slot partials + gn_finalize).  Whole-denoiser forwards at B = 8 on all three reference grids: same statistics up to the
+    rounding of the per-block partials, so agreement is to fp32 rounding.  (It measured slower than the launches it removes:
+    same-address atomic adds serialise; cm_model.cpp: plan_astat.)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    res = {}
+    for tag, extra in (("slots", {}), ("sums", {"CM_DIAG": "1", "CM_ASTAT": "1"})):
+        path = str(tmp_path / f"{tag}.npz")
+        env = dict(os.environ, **extra)
+        env.pop("CM_CONV_DBG", None)
+        r = subprocess.run([sys.executable, "-c", _UPS_CHILD.format(root=root, tests=here, path=path)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(path)
+    for gname in ("atc", "cr120", "atc2x"):
+        a, b = res["sums"][gname], res["slots"][gname]
+        assert np.isfinite(a).all() and a.shape == b.shape
+        assert not np.array_equal(a, b), "the switch did not change the statistics path"
+        assert float(np.abs(a - b).max()) <= 2e-5 * max(1.0, float(np.abs(b).max())), gname
