@@ -92,13 +92,17 @@ __global__ __launch_bounds__(256, 2) void conv_f16d_kernel(const ConvArgs a, con
 
   // ---- loads of chunk c (main: GroupNorm rows too) -------------------------------------------------------------------
   f32x4 ld[NLD], scn = {1.f, 1.f, 1.f, 1.f}, shn = {0.f, 0.f, 0.f, 0.f};
+  bool ldh = false;                                  // the loads in flight are 4 halves (8 bytes) per item: an f16 tensor (a.h16)
   auto issue = [&](int c) {
-    const float *base;
-    int Cn;
+    const float *srcp;
+    int Cn, cin;
+    bool hsrc;
     if (c < n16) {
       const bool s0 = c < n0;
       Cn = s0 ? a.C0 : a.C1;
-      base = (s0 ? a.src0 + c * 16 : a.src1 + (c - n0) * 16) + (size_t)b * Vs * Cn;
+      srcp = s0 ? a.src0 : a.src1;
+      cin = (s0 ? c : c - n0) * 16;
+      hsrc = (a.h16 & (s0 ? 1 : 2)) != 0;
       if (a.gn) {
         const float *gp = a.gn + (size_t)b * 2 * Ctot + c * 16 + 4 * q;
         scn = *reinterpret_cast<const f32x4 *>(gp);
@@ -108,21 +112,41 @@ __global__ __launch_bounds__(256, 2) void conv_f16d_kernel(const ConvArgs a, con
       const int cs = c - n16;
       const bool s0 = cs < ns0;
       Cn = s0 ? a.s2C0 : a.s2C1;
-      base = (s0 ? a.s2src0 + cs * 16 : a.s2src1 + (cs - ns0) * 16) + (size_t)b * Vs * Cn;
+      srcp = s0 ? a.s2src0 : a.s2src1;
+      cin = (s0 ? cs : cs - ns0) * 16;
+      hsrc = (a.h16 & (s0 ? 16 : 32)) != 0;
     }
-    const unsigned cb = (unsigned)Cn * 4u, q16 = 16u * (unsigned)q;
+    ldh = hsrc;
+    if (hsrc) {
+      const char *base = reinterpret_cast<const char *>(srcp) + ((size_t)b * Vs * Cn + cin) * 2;
+      const unsigned cb = (unsigned)Cn * 2u, q8 = 8u * (unsigned)q;
 #pragma unroll
-    for (int k = 0; k < NLD; ++k)
-      if (k < nit) ld[k] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(base) + (__umul24((unsigned)hoff[k], cb) + q16));
+      for (int k = 0; k < NLD; ++k)
+        if (k < nit) {
+          const cm_f32x2_t two = *reinterpret_cast<const cm_f32x2_t *>(base + (__umul24((unsigned)hoff[k], cb) + q8));
+          ld[k][0] = two[0]; ld[k][1] = two[1];
+        }
+    } else {
+      const char *base = reinterpret_cast<const char *>(srcp) + ((size_t)b * Vs * Cn + cin) * 4;
+      const unsigned cb = (unsigned)Cn * 4u, q16 = 16u * (unsigned)q;
+#pragma unroll
+      for (int k = 0; k < NLD; ++k)
+        if (k < nit) ld[k] = *reinterpret_cast<const f32x4 *>(base + (__umul24((unsigned)hoff[k], cb) + q16));
+    }
   };
   auto stage = [&](int c) {
     const bool main = c < n16;
     const f32x4 sc = scn, sh = shn;
+    const bool hl = ldh;
 #pragma unroll
     for (int k = 0; k < NLD; ++k)
       if (k < nit) {
         const int h = (tid >> 2) + 64 * k;
         f32x4 w = ld[k];
+        if (hl) {
+          const f16x4 hv4 = __builtin_bit_cast(f16x4, cm_f32x2_t{ld[k][0], ld[k][1]});
+          w = f32x4{(float)hv4[0], (float)hv4[1], (float)hv4[2], (float)hv4[3]};
+        }
         if (main && a.gn && !(a.dbg & 128)) {
           w = w * sc + sh;
           if (a.silu) { w[0] = silu_h(w[0]); w[1] = silu_h(w[1]); w[2] = silu_h(w[2]); w[3] = silu_h(w[3]); }
@@ -223,12 +247,25 @@ __global__ __launch_bounds__(256, 2) void conv_f16d_kernel(const ConvArgs a, con
 #pragma unroll
       for (int e = 0; e < 16; ++e) rs[e] = acc[j][nb][e] + bias_pre[nb] + tv_pre[nb];
       if (resb) {
+        if (a.h16 & 8) {
+          const _Float16 *rh = reinterpret_cast<const _Float16 *>(a.resid) + (size_t)b * (size_t)(a.Zo * a.Yo * a.Xo) * a.res_cs;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) rs[e] += resb[(size_t)(orow[e] >= 0 ? orow[e] : 0) * a.res_cs + (nok ? nn : 0)];
+          for (int e = 0; e < 16; ++e) rs[e] += (float)rh[(size_t)(orow[e] >= 0 ? orow[e] : 0) * a.res_cs + (nok ? nn : 0)];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) rs[e] += resb[(size_t)(orow[e] >= 0 ? orow[e] : 0) * a.res_cs + (nok ? nn : 0)];
+        }
       }
+      if (a.h16 & 4) {
+        _Float16 *oh = reinterpret_cast<_Float16 *>(a.out) + (size_t)b * (size_t)(a.Zo * a.Yo * a.Xo) * a.out_cs;
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (nok && orow[e] >= 0) outb[(size_t)orow[e] * a.out_cs + nn] = rs[e];
+        for (int e = 0; e < 16; ++e)
+          if (nok && orow[e] >= 0) oh[(size_t)orow[e] * a.out_cs + nn] = (_Float16)rs[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (nok && orow[e] >= 0) outb[(size_t)orow[e] * a.out_cs + nn] = rs[e];
+      }
       if (a.stat_part) {
         float s1 = 0.f, cnt = 0.f;
 #pragma unroll

@@ -131,9 +131,16 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvArgs a, const
     for (int reg = 0; reg < 16; ++reg) offs[reg] = outoff[blk * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) rs[reg] = acc[reg] + bias;
+    if (a.h16 & 4) {                              // f16 output tensor (reduced-precision plan)
+      _Float16 *oh = reinterpret_cast<_Float16 *>(a.out);
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg)
-      if (nok && offs[reg] >= 0) a.out[(size_t)offs[reg] * a.out_cs + n] = rs[reg];
+      for (int reg = 0; reg < 16; ++reg)
+        if (nok && offs[reg] >= 0) oh[(size_t)offs[reg] * a.out_cs + n] = (_Float16)rs[reg];
+    } else {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        if (nok && offs[reg] >= 0) a.out[(size_t)offs[reg] * a.out_cs + n] = rs[reg];
+    }
     if (a.stat_part || a.astat) {
       // GroupNorm statistics of the block (two-pass on registers; the two lane halves hold disjoint rows)
       float s1 = 0.f, cnt = 0.f;

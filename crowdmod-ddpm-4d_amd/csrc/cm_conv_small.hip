@@ -108,7 +108,13 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvArgs a, cons
         const int cx = x0 - 1 + (hp & 511), cy = y0 - 1 + ((hp >> 9) & 511), cz = z0 - 1 + ((hp >> 18) & 255);
         const bool ok = hv < cHV && cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs;
         const size_t so = ok ? ((size_t)(b * a.Zs + cz) * a.Ys + cy) * a.Xs + cx : 0;
-        v[k] = *reinterpret_cast<const f32x4 *>(src + so * Cs + c0 + 4 * q);
+        if (a.h16 & (ch < a.nch0 ? 1 : 2)) {        // f16 source tensor
+          const cm_f32x2_t two = *reinterpret_cast<const cm_f32x2_t *>(reinterpret_cast<const _Float16 *>(src) + so * Cs + c0 + 4 * q);
+          const cm_f16x4_t hv4 = __builtin_bit_cast(cm_f16x4_t, two);
+          v[k] = f32x4{(float)hv4[0], (float)hv4[1], (float)hv4[2], (float)hv4[3]};
+        } else {
+          v[k] = *reinterpret_cast<const f32x4 *>(src + so * Cs + c0 + 4 * q);
+        }
         okm |= (ok ? 1u : 0u) << k;
       }
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, pm = {1.f, 1.f, 1.f, 1.f};
@@ -138,7 +144,13 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvArgs a, cons
       f32x4 w = {0.f, 0.f, 0.f, 0.f};
       if (cz >= 0 && cz < a.Zs && cy >= 0 && cy < a.Ys && cx >= 0 && cx < a.Xs) {
         const size_t so = ((size_t)(b * a.Zs + cz) * a.Ys + cy) * a.Xs + cx;
-        w = *reinterpret_cast<const f32x4 *>(src + so * Cs + c0 + 4 * q);
+        if (a.h16 & (ch < a.nch0 ? 1 : 2)) {
+          const cm_f32x2_t two = *reinterpret_cast<const cm_f32x2_t *>(reinterpret_cast<const _Float16 *>(src) + so * Cs + c0 + 4 * q);
+          const cm_f16x4_t hv4 = __builtin_bit_cast(cm_f16x4_t, two);
+          w = f32x4{(float)hv4[0], (float)hv4[1], (float)hv4[2], (float)hv4[3]};
+        } else {
+          w = *reinterpret_cast<const f32x4 *>(src + so * Cs + c0 + 4 * q);
+        }
         if (a.gn) {
           const float *g = a.gn + (size_t)b * 2 * Ctot + cg0 + 4 * q;
           w = w * *reinterpret_cast<const f32x4 *>(g) + *reinterpret_cast<const f32x4 *>(g + Ctot);

@@ -142,7 +142,18 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
 #pragma unroll
       for (int kk = 0; kk < NLD / 2; ++kk) {
         const int k = half * (NLD / 2) + kk;
-        if (k < nit) ld[kk] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(srcb + ch * 32) + __umul24((unsigned)hoff[k], cb));
+        if (k < nit) {
+          if constexpr (F16) {
+            if (a.h16 & 1) {                        // f16 source tensor: 4 halves per item
+              const char *sh = reinterpret_cast<const char *>(a.src0) + ((size_t)b * Vs * a.C0 + 4 * q + ch * 32) * 2;
+              const cm_f32x2_t two = *reinterpret_cast<const cm_f32x2_t *>(sh + __umul24((unsigned)hoff[k], cb >> 1));
+              const f16x4 hv4 = __builtin_bit_cast(f16x4, two);
+              ld[kk] = f32x4{(float)hv4[0], (float)hv4[1], (float)hv4[2], (float)hv4[3]};
+              continue;
+            }
+          }
+          ld[kk] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(srcb + ch * 32) + __umul24((unsigned)hoff[k], cb));
+        }
       }
 #pragma unroll
       for (int kk = 0; kk < NLD / 2; ++kk) {
@@ -249,9 +260,16 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
       float rs[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) rs[e] = acc[j][nb][e] + bias_pre[nb];
+      if (F16 && (a.h16 & 4)) {
+        _Float16 *oh = reinterpret_cast<_Float16 *>(a.out) + (size_t)b * Vo * a.out_cs;
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (nok && orow[e] >= 0) outb[(size_t)orow[e] * a.out_cs + nn] = rs[e];
+        for (int e = 0; e < 16; ++e)
+          if (nok && orow[e] >= 0) oh[(size_t)orow[e] * a.out_cs + nn] = (_Float16)rs[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (nok && orow[e] >= 0) outb[(size_t)orow[e] * a.out_cs + nn] = rs[e];
+      }
       if (a.stat_part || a.astat) {
         float s1 = 0.f, cnt = 0.f;
 #pragma unroll

@@ -34,6 +34,7 @@ typedef float cm_f32x2_t __attribute__((ext_vector_type(2)));
 typedef float cm_f32x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 cm_bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned cm_u32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 cm_f16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned cm_cvt_pk_bf16(float a, float b) {
   const cm_f32x2_t v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, cm_bf16x2_t));
@@ -106,6 +107,12 @@ struct ConvArgs {
   int f16;             // 1: wfrag holds f16 fragments (4 halves per lane and step); specialised parity form only
   int zsplit;          // weight gradient of a 27-tap layer on a two-plane grid: mtab rows [0,32) are plane 0, [32,64) plane 1,
                        //   and a row block skips the z tap that multiplies its padding plane (18 of 27 taps, as the forward)
+  // Round 4 -- f16 ACTIVATIONS in HBM (reduced-precision plan, BASELINE configs[4]; the reference's autocast makes every conv
+  // output fp16, ddpm.py:116-120): bit mask of the tensors of this launch that are stored as _Float16 instead of float (same
+  // channels-last layout, same element strides): 1 src0, 2 src1, 4 out, 8 resid, 16 s2src0, 32 s2src1.  Only kernels that
+  // implement it ever receive a non-zero mask (cm_model.cpp: plan_h16): conv_f16d, conv_first (out), conv_ups (f16 form),
+  // conv_smalln (src).  Accumulation, GroupNorm statistics (taken from the fp32 accumulators), SiLU and the sampler stay fp32.
+  int h16;
   // Round 4 -- GroupNorm statistics WITHOUT the gn_finalize launch (inference plan).  Producer side: instead of slot partials,
   // every 32-row block ADDS its per-channel sums to astat[b][astat_C][3] (64-bit fixed point: sum x * 2^16 as two's complement,
   // floor(sum x^2 / 2^32), (sum x^2 mod 2^32) * 2^20): integer adds are exact and order-independent, so the totals are

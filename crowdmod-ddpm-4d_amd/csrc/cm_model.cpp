@@ -72,6 +72,7 @@ struct Act {
   float *cnt = nullptr;   // [B][nslots] rows behind each slot
   int nslice = 1;         // slots when the stand-alone statistics kernel fills them
   int nslots = 0;         // slots of the last producer (fused conv epilogue or stats kernel)
+  bool h16 = false;       // reduced-precision plan: the tensor is stored as _Float16 (same layout and strides; plan_h16)
   int aoff = -1;          // >= 0: GroupNorm statistics of this tensor go to the accumulator rows (cm_model::astat_all, channel offset aoff)
                           //   in the inference plan -- producers add exact fixed-point sums, consumers finalise, no gn_finalize launch
   int V() const { return Z * Y * X; }
@@ -419,6 +420,26 @@ std::vector<float> parity_weights(const std::vector<float> &Wi, int Co, int Ci) 
 }
 
 uint16_t f32_to_f16_bits(float f);
+// IEEE binary16 bits -> float (exact)
+static inline float f16_bits_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, x;
+  if (exp == 0) {
+    if (man == 0) { x = sign; }
+    else {
+      int e = -1;
+      do { ++e; man <<= 1; } while (!(man & 0x400u));
+      x = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+    }
+  } else if (exp == 31) {
+    x = sign | 0x7f800000u | (man << 13);
+  } else {
+    x = sign | ((exp + 127 - 15) << 23) | (man << 13);
+  }
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
 
 // f16 version of pack_conv_weights (same order, 4 halves per lane and step), returned as floats holding two halves each
 std::vector<float> pack_conv_weights_f16(const float *W, int Co, int Ci, int ntaps, int Ci_pad, int CK, int NB) {
@@ -1369,6 +1390,38 @@ int build_ops(cm_model *m) {
 }
 
 // Time-embedding tables for all 1000 rows (embeddings.py:24-30 + layers.py:35,62).
+// f16 ACTIVATIONS (round 4; reduced-precision plan = BASELINE configs[4]; the reference's autocast stores every conv output as
+// fp16, ddpm.py:116-120): a tensor is stored as _Float16 when the kernel that produces it can write f16 and every kernel that reads
+// it can read f16 -- the direct f16 conv (source, residual, fused skip source, output), the first conv (output), the f16 stage-once
+// upsample conv (source, output) and the last conv (source).  That covers the full- and half-resolution tensors of a grid with >= 4
+// planes at half resolution except the inputs of the two stride-2 convs; quarter-resolution tensors (2 % of the bytes) stay fp32.
+// GroupNorm statistics come from the fp32 accumulators of the producer; a kernel that cannot honour a flagged tensor fails loudly
+// (run_conv) instead of misreading it.  CM_NO_H16 under CM_DIAG=1 keeps fp32 storage (A/B runs).
+int plan_h16(cm_model *m) {
+  if (m->precision != CM_PRECISION_F16 || cm::diag_env("CM_NO_H16")) return 0;
+  auto writes16 = [](const Op &o) { return o.kind == OP_CONV && o.ks <= 1 && ((o.wino && o.f16d) || o.first_k || (o.ups && o.d_wups16)); };
+  for (auto &ap : m->acts) {
+    Act *a = ap.get();
+    bool ok = false;
+    for (const Op &o : m->ops)
+      if (o.kind == OP_CONV && o.out_act == a && !o.skip_if_fused) ok = writes16(o);
+    if (!ok) continue;
+    for (const Op &o : m->ops) {
+      if (!ok) break;
+      if (o.kind == OP_ATTNBLK && o.ab_x == a) ok = false;
+      if (o.kind == OP_ATTN && (o.qkv == a->d || o.aout == a->d)) ok = false;
+      if (o.kind != OP_CONV) continue;
+      const bool f16d = o.wino && o.f16d && o.ks <= 1;
+      if (o.skip_if_fused) continue;                            // the stand-alone skip conv: absorbed by the block's conv_2 at inference
+      if (o.in0 == a || o.in1 == a) ok = ok && (f16d || (o.in0 == a && !o.in1 && o.ups && o.d_wups16 && o.ks <= 1) || (o.small_n && o.ks <= 1));
+      if (o.resid_act == a) ok = ok && f16d;
+      if (o.skip0 == a || o.skip1 == a) ok = ok && f16d && o.d_w16d_skip;
+    }
+    a->h16 = ok;
+  }
+  return 0;
+}
+
 // Which GroupNorm finalisations of the INFERENCE plan can go without their launch (round 4): the source tensors' producers add
 // exact fixed-point sums to accumulator rows (cm_stat_atomic), the consuming conv finalises them in its prologue (six-term Winograd
 // kernel) or through a fall-back launch that costs what gn_finalize cost.  Eligible: fp32 plan; every source tensor produced by an
@@ -1566,8 +1619,13 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   op.prof_B = B;
   ca.nts = (B + ca.bs - 1) / ca.bs;
   const size_t Vs = (size_t)ca.Zs * ca.Ys * ca.Xs, Vo = (size_t)ca.Zo * ca.Yo * ca.Xo;
-  ca.src0 += (size_t)b0 * Vs * ca.C0;
-  if (ca.src1) ca.src1 += (size_t)b0 * Vs * ca.C1;
+  // f16 tensors of the reduced-precision plan (plan_h16): half the bytes per element, so half the float offset; the mask tells the
+  // kernel which of its tensors they are (the training forward never sees them: training refuses f16 handles)
+  auto is16 = [&](const Act *t) { return t && t->h16 && !m->train_fwd; };
+  auto adv = [&](const float *p, size_t elems, bool h) { return p + (h ? elems / 2 : elems); };
+  ca.h16 = (is16(op.in0) ? 1 : 0) | (is16(op.in1) ? 2 : 0) | (is16(op.out_act) ? 4 : 0) | (is16(op.resid_act) ? 8 : 0);
+  ca.src0 = adv(ca.src0, (size_t)b0 * Vs * ca.C0, is16(op.in0));
+  if (ca.src1) ca.src1 = adv(ca.src1, (size_t)b0 * Vs * ca.C1, is16(op.in1));
   if (ca.gn) ca.gn += (size_t)b0 * 2 * (ca.C0 + ca.C1);
   ca.tidx += b0;
   if (m->train_fwd && op.pm_off >= 0) {
@@ -1578,16 +1636,17 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     ca.temb = m->train_temb + op.temb_off;
     ca.tidx = m->train_iota + b0;
   }
-  if (ca.resid) ca.resid += (size_t)b0 * Vo * ca.res_cs;
+  if (ca.resid) ca.resid = adv(ca.resid, (size_t)b0 * Vo * ca.res_cs, is16(op.resid_act));
   if (op.d_s2w && !m->train_fwd) {
     if (!op.wino && 32 * op.MB > cm::conv_halo_voxels(ca)) return fail("fused skip conv: tile rows exceed the staged box");
     ca.s2w = op.d_s2w;
-    ca.s2src0 = op.skip0->d + (size_t)b0 * Vo * op.skip0->C; ca.s2C0 = op.skip0->C;
-    ca.s2src1 = op.skip1 ? op.skip1->d + (size_t)b0 * Vo * op.skip1->C : nullptr; ca.s2C1 = op.skip1 ? op.skip1->C : 0;
+    ca.s2src0 = adv(op.skip0->d, (size_t)b0 * Vo * op.skip0->C, is16(op.skip0)); ca.s2C0 = op.skip0->C;
+    ca.s2src1 = op.skip1 ? adv(op.skip1->d, (size_t)b0 * Vo * op.skip1->C, is16(op.skip1)) : nullptr; ca.s2C1 = op.skip1 ? op.skip1->C : 0;
+    ca.h16 = (ca.h16 & ~8) | (is16(op.skip0) ? 16 : 0) | (is16(op.skip1) ? 32 : 0);
     ca.resid = nullptr;
     ca.bias = op.d_bias_fused;
   }
-  ca.out += (size_t)b0 * Vo * ca.out_cs;
+  ca.out = const_cast<float *>(adv(ca.out, (size_t)b0 * Vo * ca.out_cs, is16(op.out_act)));
   int ns = 0;
   if (op.stat_act) {
     ns = ca.ntz * ca.nty * ca.ntx * op.MB * (ca.par ? 8 : 1);
@@ -1609,6 +1668,12 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   // accumulate; its fragments follow every optimizer step)
   const bool wino_b6 = take_wino && !wino_f16 && op.d_wwino_b6 && !(m->train_fwd && (no_train_b6 || m->precision == CM_PRECISION_F16)) &&
                        cm::conv_wino_b6_ok(ca.bz, ca.by, ca.bx, ca.Co, ca.Zo);
+  if (ca.h16) {
+    // only these kernels read / write f16 tensors; anything else here would misread them silently
+    const bool ok16 = take_f16d || (take_ups && op.d_wups16 && !(ca.h16 & ~5)) || (op.first_k && !(ca.h16 & ~4) && op.ks <= 1 && !take_ups && !op.wino) ||
+                      (op.small_n && !(ca.h16 & ~3) && op.ks <= 1 && !take_ups && !op.wino && !op.first_k);
+    if (!ok16) return fail("conv %s: f16 tensors (mask %d) reach a kernel without f16 tensor support", op.label.c_str(), ca.h16);
+  }
   // consumer side: the GroupNorm of the input comes from the producers' accumulator rows -- finalised inside the six-term
   // Winograd kernel, or by a fall-back launch that writes the rows gn_finalize would have written
   if (!m->train_fwd && m->astat_all && op.gn_op >= 0 && m->ops[op.gn_op].atomic && ca.gn) {
@@ -2146,6 +2211,7 @@ int cm_model_finalize(cm_model *m) {
   if (dev_alloc(m, (void **)&m->tbuf, B * sizeof(long long))) return 1;
   CM_HIP(hipMemset(m->tbuf, 0, B * sizeof(long long)));
   if (build_ops(m)) return 1;
+  if (plan_h16(m)) return 1;
   if (plan_astat(m)) return 1;
   if (build_time_table(m)) return 1;
   const size_t per = (size_t)m->per_sample();
@@ -2255,6 +2321,21 @@ int cm_debug_activation(cm_model *m, const char *name, float *h_out, int64_t cap
   const int C = a->C;
   const int64_t n = (int64_t)B * C * a->V();
   if (capacity < n) return fail("capacity %lld < %lld", (long long)capacity, (long long)n);
+  if (a->h16) {
+    // f16 tensor of the reduced-precision plan: fetched as stored, converted and re-laid [B,C,H,W,L] on the host (test hook)
+    std::vector<uint16_t> raw((size_t)n);
+    CM_HIP(hipStreamSynchronize(m->stream));
+    CM_HIP(hipMemcpy(raw.data(), a->d, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b)
+      for (int z = 0; z < a->Z; ++z)
+        for (int y = 0; y < a->Y; ++y)
+          for (int x = 0; x < a->X; ++x)
+            for (int c = 0; c < C; ++c)
+              h_out[((((size_t)b * C + c) * a->Y + y) * a->X + x) * a->Z + z] =
+                  f16_bits_to_f32(raw[((((size_t)b * a->Z + z) * a->Y + y) * a->X + x) * C + c]);
+    if (shape) { shape[0] = B; shape[1] = C; shape[2] = a->Y; shape[3] = a->X; shape[4] = a->Z; }
+    return 0;
+  }
   float *tmp = nullptr;
   CM_HIP(hipMalloc((void **)&tmp, (size_t)n * sizeof(float)));
   hipError_t e = cm::launch_cl_to_ref(a->d, a->C, tmp, B, C, a->Z, a->Y, a->X, m->stream);
