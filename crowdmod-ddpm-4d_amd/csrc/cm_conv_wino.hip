@@ -692,15 +692,18 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
   const int n2a = SKIP ? a.s2C0 >> 5 : 0, n2 = SKIP ? (a.s2C0 + a.s2C1) >> 5 : 0;
   const int slot = p * 4 + wave;
 
-  const bool norm = a.gn != nullptr || a.gs0 != nullptr;     // GroupNorm (+ SiLU) on load
+  const bool own_gn = a.gs0 != nullptr || a.gp0 != nullptr;  // the GroupNorm of the input is finalised in this workgroup
+  const bool norm = a.gn != nullptr || own_gn;               // GroupNorm (+ SiLU) on load
   for (int b = g0; b < a.B; b += G) {
     const bool more_b = b + G < a.B;
     const float tv_pre = a.temb ? a.temb[(size_t)a.tidx[b] * a.temb_stride + nc_epi] : 0.f;
-    if (a.gs0) {
-      // the GroupNorm of this sample's input finalised HERE from the producers' accumulators (no gn_finalize launch): the halo
-      // loads of the first chunk are already in flight, the rows are read from LDS in step A
+    if (own_gn) {
+      // the GroupNorm of this sample's input finalised HERE (no gn_finalize launch) from the producers' slot partials (few slots:
+      // half / quarter resolution) or accumulator rows: the halo loads of the first chunk are already in flight, the rows are
+      // read from LDS in step A
       __syncthreads();                            // (the previous sample's last step A has read its rows, its epilogue the exchange buffer)
-      cm_gn_rows_from_sums(a, b, (int)Vs, GNL, reinterpret_cast<double *>(U), tid, NT);   // (U is free here: scratch)
+      if (a.gp0) cm_gn_rows_from_slots(a, b, (int)Vs, GNL, U, tid, NT);                     // (U is free here: scratch)
+      else cm_gn_rows_from_sums(a, b, (int)Vs, GNL, reinterpret_cast<double *>(U), tid, NT);
       __syncthreads();
     }
     f32x16 acc[4];
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
     for (int ch = 0; ch < nchunks; ++ch) {
       // ---- step A: this chunk's halo voxels -> activated image R ------------------------------------------
       f32x4 sc1 = scn, sh1 = shn;
-      if (a.gs0) {
+      if (own_gn) {
         const int cb0 = (ch < n0 ? ch * CS : a.C0 + (ch - n0) * CS) + 4 * aq;
         sc1 = *reinterpret_cast<const f32x4 *>(GNL + cb0);
         sh1 = *reinterpret_cast<const f32x4 *>(GNL + Ctot + cb0);
@@ -1194,7 +1197,7 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
   // sample lanes balance worse (85 vs 79 us).  CM_WINO_P=1 under CM_DIAG forces it everywhere for A/B runs.
   static const bool all_p = cm::diag_env("CM_WINO_P") != nullptr;
   if (conv_wino_two_step(a.bz, a.by, a.bx, f16, nbw) && !no_p && (nbw == 2 || all_p || b6)) {
-    const size_t ldsp = conv_wino_p_lds(a.bz, a.by, a.bx, f16, nbw, b6) + (a.gs0 ? (size_t)2 * (a.C0 + a.C1) * sizeof(float) : 0);
+    const size_t ldsp = conv_wino_p_lds(a.bz, a.by, a.bx, f16, nbw, b6) + ((a.gs0 || a.gp0) ? (size_t)2 * (a.C0 + a.C1) * sizeof(float) : 0);
     const int ntp = a.ntz * a.nty * a.ntx, nz = (a.Co + 31) / 32 / nbw;
     const int per_cu = (nbw == 1 && 2 * ldsp <= 160 * 1024) ? 2 : 1;
     const int slots = wino_cu_count() * per_cu;

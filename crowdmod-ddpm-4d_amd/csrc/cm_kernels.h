@@ -125,6 +125,11 @@ struct ConvArgs {
   const float *gs_gamma, *gs_beta;       //   affine of this layer's GroupNorm over the C0 + C1 input channels
   int gs_groups;
   float gs_eps;
+  // Round 4 -- the same consumer-side finalisation from the producers' SLOT partials, when they are few (half / quarter
+  // resolution: <= 32 slots per sample): part [B][gns][C][2] (mean, M2), cnt [B][gns], from sample 0 of this launch, as
+  // gn_finalize reads them (conv_qr2 has done this since round 3).  Shares gs_gamma / gs_beta / gs_groups / gs_eps.
+  const float *gp0, *gc0, *gp1, *gc1;
+  int gns0, gns1;
 };
 #ifdef __HIPCC__
 // ---- statistics accumulators (ConvArgs::astat) ----------------------------------------------------------------------------
@@ -161,6 +166,52 @@ __device__ __forceinline__ void cm_stat_read(const unsigned long long *acc, doub
 // reads its channel's three words (ONE round trip for the whole workgroup; a loop over the group's channels per thread paid one
 // per channel, 6 us per workgroup) into `scratch` [Ctot][2] doubles in LDS; pass 2 -- every channel sums its group's entries
 // (4 ... 24 LDS reads) and finishes in registers.  V = voxels per sample.  The caller synchronises before it reads `rows`.
+// Chan et al. pairwise combination of (n, mean, M2) triples (cm_misc.hip: chan_combine; same arithmetic)
+__device__ __forceinline__ void cm_chan_combine(float &n, float &mean, float &m2, float nb, float meanb, float m2b) {
+  if (nb == 0.f) return;
+  const float nt = n + nb;
+  const float d = meanb - mean;
+  const float f = nb * __builtin_amdgcn_rcpf(nt);
+  mean += d * f;
+  m2 += m2b + d * d * n * f;
+  n = nt;
+}
+// Consumer prologue, slot form (ConvArgs::gp0): rows[2 (C0 + C1)] of sample `b` from the producers' slot partials.  Called by all
+// `nth` threads (one barrier inside).  Pass 1: thread c merges the <= 32 slots of its channel in slot order (their loads issued
+// together) into scratch[Ctot][2] (mean, M2 over the V voxels); pass 2: every channel merges its group's channels in channel order.
+__device__ __forceinline__ void cm_gn_rows_from_slots(const ConvArgs &a, int b, int V, float *rows, float *scratch, int tid, int nth) {
+  const int Ctot = a.C0 + a.C1, cg = Ctot / a.gs_groups;
+  for (int c = tid; c < Ctot; c += nth) {
+    const bool s0 = c < a.C0;
+    const float *p = s0 ? a.gp0 : a.gp1, *nn = s0 ? a.gc0 : a.gc1;
+    const int ns = s0 ? a.gns0 : a.gns1, Cx = s0 ? a.C0 : a.C1, cc = s0 ? c : c - a.C0;
+    float N = 0.f, M = 0.f, S2 = 0.f;
+    for (int s8 = 0; s8 < ns; s8 += 8) {            // eight slots per round, all their loads in flight together
+      float cn[8];
+      cm_f32x2_t q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int sl = s8 + u < ns ? s8 + u : ns - 1;
+        cn[u] = s8 + u < ns ? nn[(size_t)b * ns + sl] : 0.f;
+        q[u] = *reinterpret_cast<const cm_f32x2_t *>(p + (((size_t)b * ns + sl) * Cx + cc) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cm_chan_combine(N, M, S2, cn[u], q[u][0], q[u][1]);
+    }
+    scratch[2 * c] = M;
+    scratch[2 * c + 1] = S2;
+  }
+  __syncthreads();
+  for (int c = tid; c < Ctot; c += nth) {
+    const int g0 = (c / cg) * cg;
+    float N = 0.f, M = 0.f, S2 = 0.f;
+    for (int k = g0; k < g0 + cg; ++k) cm_chan_combine(N, M, S2, (float)V, scratch[2 * k], scratch[2 * k + 1]);
+    const float rstd = rsqrtf(S2 / N + a.gs_eps);
+    const float sc = rstd * a.gs_gamma[c];
+    rows[c] = sc;
+    rows[Ctot + c] = a.gs_beta[c] - M * sc;
+  }
+}
 __device__ __forceinline__ void cm_gn_rows_from_sums(const ConvArgs &a, int b, int V, float *rows, double *scratch, int tid, int nth) {
   const int Ctot = a.C0 + a.C1, cg = Ctot / a.gs_groups;
   for (int c = tid; c < Ctot; c += nth) {
@@ -238,6 +289,7 @@ bool conv_wino_tile_ok(int bz, int by, int bx);
 bool conv_wino_ok(const ConvArgs &a);
 size_t conv_wino_lds(int bz, int by, int bx, bool f16, int nbw);
 int conv_wino_nbw(int bz, int Co);
+bool conv_wino_two_step(int bz, int by, int bx, bool f16, int nbw);
 // f16: a.wfrag holds the f16 packing (3 groups per chunk and wave, 8 halves per lane): fp32 accumulate, f16 operands
 hipError_t launch_conv_wino(const ConvArgs &a, bool f16, hipStream_t st);
 // six-term bf16 form (a.f16 = 2, wfrag = pack_wino_b6 fragments): two-tile table-driven kernel only

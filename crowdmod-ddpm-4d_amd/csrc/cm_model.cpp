@@ -134,6 +134,9 @@ struct Op {
   bool train_qr = false;        // the training forward may take conv_qr2 as well (set by train_setup once the geometry is checked)
   long long wqr_floats = 0;
   bool qr_consumer = false; // OP_GNFIN whose only consumer is a qr conv: that kernel finalises the statistics itself
+  bool from_slots = false;  // OP_GNFIN (inference plan): its only consumer is a six-term Winograd conv that finalises the statistics from the
+                            //   producers' slot partials itself when they are few (run_conv decides per launch; set by plan_slot_consumers)
+  bool fin_skipped[4] = {false, false, false, false};   // per batch lane: this step's launch of the op was skipped on that promise
   bool atomic = false;      // OP_GNFIN (inference plan): its source tensors keep accumulator statistics and its consumers finalise them -- no launch
   bool first_k = false;     // the UNet's first conv on its dedicated kernel (cm_conv_io.hip)
   int first_cin = 4;        //   input channels it contracts per tap: 4 (C <= 4) or 8
@@ -1422,6 +1425,25 @@ int plan_h16(cm_model *m) {
   return 0;
 }
 
+// GroupNorm finalisations whose only consumer is a Winograd conv of the table-driven kernel: that kernel can merge the producers'
+// slot partials itself when they are few (<= 32 per sample: the half- and quarter-resolution layers) -- decided per launch in
+// run_ops / run_conv, here only the structural part.  (conv_qr2 has finalised its own input this way since round 3.)
+int plan_slot_consumers(cm_model *m) {
+  if (cm::diag_env("CM_NO_SLOT_GN")) return 0;
+  const int nops = (int)m->ops.size();
+  for (int i = 0; i < nops; ++i) {
+    Op &g = m->ops[i];
+    if (g.kind != OP_GNFIN || g.qr_consumer || g.in_attn_block || g.atomic) continue;
+    int ncons = 0, cons = -1;
+    for (int j = 0; j < nops; ++j)
+      if (m->ops[j].kind == OP_CONV && m->ops[j].gn_op == i) { ++ncons; cons = j; }
+    if (ncons != 1) continue;
+    const Op &c = m->ops[cons];
+    g.from_slots = c.wino && !c.qr && c.ks <= 1 && !c.f16d && !c.b6d && !c.skip_if_fused && (c.d_wwino_b6 || c.d_wwino16);
+  }
+  return 0;
+}
+
 // Which GroupNorm finalisations of the INFERENCE plan can go without their launch (round 4): the source tensors' producers add
 // exact fixed-point sums to accumulator rows (cm_stat_atomic), the consuming conv finalises them in its prologue (six-term Winograd
 // kernel) or through a fall-back launch that costs what gn_finalize cost.  Eligible: fp32 plan; every source tensor produced by an
@@ -1655,7 +1677,6 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     ca.stat_ns = ns;
     ca.stat_part = op.stat_act->part + (size_t)b0 * ns * ca.stat_C * 2;
     ca.stat_cnt = op.stat_act->cnt + (size_t)b0 * ns;
-    op.stat_act->nslots = ns;
   }
   // ---- which kernel will run (needed up front: only some kernels speak the accumulator statistics of round 4) -------------------
   static const bool no_train_b6 = cm::diag_env("CM_NO_TRAIN_B6") != nullptr;
@@ -1663,6 +1684,11 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   const bool take_f16d = op.ks <= 1 && !take_ups && op.wino && op.f16d && !m->train_fwd;
   const bool take_b6d = op.ks <= 1 && !take_ups && !take_f16d && op.wino && op.b6d && !m->train_fwd && m->precision != CM_PRECISION_F16;
   const bool take_wino = op.ks <= 1 && !take_ups && !take_f16d && !take_b6d && op.wino;
+  // The slot count of the output tensor is written ONCE per launch with the count of the kernel that runs: the batch lanes
+  // enqueue from two host threads, and the other lane's gn_finalize reads it -- a generic count first and the upsample /
+  // direct kernel's own count afterwards left a window in which that reader saw the wrong number of slots (a rare wrong
+  // statistic: the one-off failure of the two-lane bit-identity test in round 4).  All lanes write the same value.
+  if (op.stat_act && op.ks <= 1 && !take_ups && !take_f16d && !take_b6d) op.stat_act->nslots = ns;
   const bool wino_f16 = take_wino && op.d_wwino16 && !m->train_fwd;     // reduced-precision plan: f16 operands in the inference forward
   // two-tile layers / the full-resolution tile, fp32 plan: six-term bf16 products (the training forward as well: exact splits, fp32
   // accumulate; its fragments follow every optimizer step)
@@ -1686,6 +1712,26 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     } else {
       CM_HIP(cm::launch_gn_from_sums(ca, (int)Vs, const_cast<float *>(ca.gn), st));
       ca.gs0 = ca.gs1 = nullptr;
+    }
+  }
+  // ... or from their slot partials when run_ops skipped the gn_finalize launch on that promise (few slots)
+  if (!m->train_fwd && op.gn_op >= 0 && m->ops[op.gn_op].fin_skipped[slab & 3] && ca.gn) {
+    const Op &g = m->ops[op.gn_op];
+    const Act *g0 = g.g0, *g1 = g.g1;
+    const int nbw = cm::conv_wino_nbw(ca.bz, ca.Co);
+    const bool p_kernel = take_wino && cm::conv_wino_two_step(ca.bz, ca.by, ca.bx, wino_f16, nbw) && (nbw == 2 || wino_b6);
+    if (p_kernel) {
+      ca.gp0 = g0->part + (size_t)b0 * g0->nslots * g0->C * 2; ca.gc0 = g0->cnt + (size_t)b0 * g0->nslots; ca.gns0 = g0->nslots;
+      if (g1) { ca.gp1 = g1->part + (size_t)b0 * g1->nslots * g1->C * 2; ca.gc1 = g1->cnt + (size_t)b0 * g1->nslots; ca.gns1 = g1->nslots; }
+      ca.gs_gamma = g.gamma; ca.gs_beta = g.beta; ca.gs_groups = GN_GROUPS; ca.gs_eps = GN_EPS;
+      ca.gn = nullptr;
+    } else {
+      // (a kernel that cannot: the launch that was skipped, now)
+      const int Ct = g0->C + (g1 ? g1->C : 0);
+      CM_HIP(cm::launch_gn_finalize(g0->part + (size_t)b0 * g0->nslots * g0->C * 2, g0->cnt + (size_t)b0 * g0->nslots, g0->nslots, g0->C,
+                                    g1 ? g1->part + (size_t)b0 * g1->nslots * g1->C * 2 : nullptr, g1 ? g1->cnt + (size_t)b0 * g1->nslots : nullptr,
+                                    g1 ? g1->nslots : 0, g1 ? g1->C : 0, g0->V(), g.gamma, g.beta, GN_GROUPS, GN_EPS,
+                                    g.gn_out + (size_t)b0 * 2 * Ct, nullptr, B, st));
     }
   }
   // producer side: this launch adds its output's statistics to the accumulator rows instead of writing slot partials
@@ -1871,6 +1917,14 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
       case OP_GNFIN: {
         if (op.qr_consumer && !m->train_fwd) break;   // its consumer finalises the statistics itself (cm_conv_qr.hip)
         if (op.atomic && !m->train_fwd) break;        // accumulator statistics: finalised by the consuming conv (run_conv)
+        op.fin_skipped[slab & 3] = false;
+        // (<= 16 slots: measured -0.7 % on the ATC step, -1.6 % on the 24x72 f16 plan; HERMES-CR-120's half resolution has 24 slots
+        //  per tensor and up to 192 channels -- there the merge in 256 workgroups cost more than the launch, +0.5 %)
+        if (op.from_slots && !m->train_fwd && op.g0->nslots <= 16 && (!op.g1 || op.g1->nslots <= 16) &&
+            (!op.g1 || op.g1->V() == op.g0->V())) {
+          op.fin_skipped[slab & 3] = true;            // few slots: the consuming Winograd conv merges them in its prologue (run_conv)
+          break;
+        }
         { static const bool skip = cm::diag_env("CM_SKIP_GNFIN") != nullptr; if (skip) break; }   // timing bound only (stale rows)
         if (op.g1 && op.g1->V() != op.g0->V()) return fail("concat sources disagree on voxel count");
         const Act *g0 = op.g0, *g1 = op.g1;
@@ -2213,6 +2267,7 @@ int cm_model_finalize(cm_model *m) {
   if (build_ops(m)) return 1;
   if (plan_h16(m)) return 1;
   if (plan_astat(m)) return 1;
+  if (plan_slot_consumers(m)) return 1;
   if (build_time_table(m)) return 1;
   const size_t per = (size_t)m->per_sample();
   const size_t per_past = (size_t)c.in_channels * c.rows * c.cols * c.past_len;

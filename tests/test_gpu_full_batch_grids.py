@@ -346,3 +346,31 @@ def test_accumulator_statistics_agree_with_the_gn_finalize_launches(tmp_path):
         assert np.isfinite(a).all() and a.shape == b.shape
         assert not np.array_equal(a, b), "the switch did not change the statistics path"
         assert float(np.abs(a - b).max()) <= 2e-5 * max(1.0, float(np.abs(b).max())), gname
+
+
+def test_groupnorm_finalised_in_the_winograd_prologue_agrees_with_the_gn_finalize_launch(tmp_path):
+    """Round 4: a Winograd conv whose source tensors carry <= 16 statistics slots per sample (the half-resolution layers of the ATC
+    grid, the quarter resolution of the 24x72 grid) merges the slot partials in its own prologue -- no gn_finalize launch (as conv_qr2
+    has done at the lowest resolution since round 3).  Against the plan with the launches (child process, CM_DIAG=1 CM_NO_SLOT_GN=1):
+    same partials, a different merge order, so whole-denoiser forwards agree to fp32 rounding and are not bit-identical on the grids
+    where the path is taken (ATC, 24x72; HERMES-CR-120's half resolution has 24 slots and keeps the launch)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    res = {}
+    for tag, extra in (("prologue", {}), ("launch", {"CM_DIAG": "1", "CM_NO_SLOT_GN": "1"})):
+        path = str(tmp_path / f"{tag}.npz")
+        env = dict(os.environ, **extra)
+        env.pop("CM_CONV_DBG", None)
+        r = subprocess.run([sys.executable, "-c", _UPS_CHILD.format(root=root, tests=here, path=path)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(path)
+    for gname in ("atc", "cr120", "atc2x"):
+        a, b = res["prologue"][gname], res["launch"][gname]
+        assert np.isfinite(a).all() and a.shape == b.shape
+        if gname != "cr120":
+            assert not np.array_equal(a, b), "the switch did not change the finalisation path"
+        assert float(np.abs(a - b).max()) <= 2e-5 * max(1.0, float(np.abs(b).max())), gname
