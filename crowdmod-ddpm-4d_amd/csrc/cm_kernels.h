@@ -366,6 +366,14 @@ void conv_b6d_tables(int Z, int Y, int X, int bz, int by, int bx, int nw, int mb
 // split fragments from the layer's fp32 weights in the REFERENCE layout [Co][Ci][kH][kW][kL] (or [Co][Ci], taps = 1), e.g. after an optimizer step
 hipError_t launch_b6d_repack(const float *w, float *w6, int Co, int Ci, int taps, int NB, hipStream_t st);
 
+// The UNet's last conv (32 -> C <= 4 channels) on the matrix core with the 27 taps packed into the columns (cm_conv_fin.hip):
+// a.by / a.bx = in-plane tile of conv_fin_pick; wfin = launch_fin_pack fragments (three bf16 terms, or one f16 term with f16 = true)
+bool conv_fin_pick(int Y, int X, int *by, int *bx);
+bool conv_fin_ok(const ConvArgs &a);
+hipError_t launch_conv_fin(const ConvArgs &a, const float *wfin, bool f16, hipStream_t st);
+hipError_t launch_fin_pack(const float *w_ref /*[Co][32][3][3][3] reference layout, device*/, float *wfin, int Co, bool f16, hipStream_t st);
+constexpr size_t CM_FIN_W_FLOATS = 4 * 2 * 3 * 64 * 4;   // fragment floats (six-term form; the f16 form uses a third)
+
 // ---- small kernels --------------------------------------------------------
 // Per-(sample, slice, channel) mean and M2 of a channels-last tensor.
 //   part [B][nslice][C][2]

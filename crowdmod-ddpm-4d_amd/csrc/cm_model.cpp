@@ -144,6 +144,9 @@ struct Op {
   bool small_n = false;     // <= 8 output channels: vector-ALU kernel (cm_conv_small.hip)
   float *d_wsmall = nullptr;
   int small_nco = 4;
+  bool fin = false;         // the last conv on the matrix core, taps packed into the columns (cm_conv_fin.hip); falls back to small_n
+  int fin_by = 0, fin_bx = 0;
+  float *d_wfin = nullptr, *d_wfin16 = nullptr, *d_wfin_src = nullptr;   // six-term / f16 fragments; device copy of the reference-layout weights
   float *d_zero_bias = nullptr;
   const Act *out_act = nullptr, *resid_act = nullptr;
   double flops_per_sample = 0;
@@ -1047,6 +1050,18 @@ int add_conv(cm_model *m, const ConvSpec &s) {
             if (cig < Ci_ref) ws[(((size_t)ch * 27 + t) * a.CK + ci) * nco + co] = wi[((size_t)co * Ci_ref + cig) * 27 + t];
           }
     if (upload(m, ws, &op.d_wsmall)) return 1;
+    // the same layer on the matrix core (round 4): 27 taps x 4 channels = 108 columns of a GEMM over the 32 input channels
+    if (s.Co <= 4 && Ci_ref == 32 && Ci_pad == 32 && !s.s1 && !cm::diag_env("CM_NO_FIN") && cm::conv_fin_pick(s.out->Y, s.out->X, &op.fin_by, &op.fin_bx)) {
+      if (upload(m, w.host, &op.d_wfin_src)) return 1;
+      if (dev_alloc(m, (void **)&op.d_wfin, cm::CM_FIN_W_FLOATS * sizeof(float))) return 1;
+      CM_HIP(cm::launch_fin_pack(op.d_wfin_src, op.d_wfin, s.Co, false, m->stream));
+      if (m->precision == CM_PRECISION_F16) {
+        if (dev_alloc(m, (void **)&op.d_wfin16, cm::CM_FIN_W_FLOATS * sizeof(float))) return 1;
+        CM_HIP(cm::launch_fin_pack(op.d_wfin_src, op.d_wfin16, s.Co, true, m->stream));
+      }
+      CM_HIP(hipStreamSynchronize(m->stream));
+      op.fin = true;
+    }
   }
   if (op.wino) {
     std::vector<float> ww;
@@ -1822,7 +1837,17 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     to_astat();
     CM_HIP(cm::launch_conv_first(ca, op.first_cin, op.d_wfirst, st));
   } else if (op.small_n) {
-    CM_HIP(cm::launch_conv_smalln(ca, op.MB, op.d_wsmall, st));
+    bool done = false;
+    if (op.fin) {
+      cm::ConvArgs fa = ca;
+      fa.by = op.fin_by; fa.bx = op.fin_bx;
+      const bool f16 = op.d_wfin16 && !m->train_fwd;
+      if (cm::conv_fin_ok(fa)) {
+        CM_HIP(cm::launch_conv_fin(fa, f16 ? op.d_wfin16 : op.d_wfin, f16, st));
+        done = true;
+      }
+    }
+    if (!done) CM_HIP(cm::launch_conv_smalln(ca, op.MB, op.d_wsmall, st));
   } else {
     if (op.d_w1x1_16 && !m->train_fwd && cm::conv1x1_f16_ok(ca, op.NB)) {
       ca.wfrag = op.d_w1x1_16;
@@ -2955,6 +2980,10 @@ static int exec_flops_split(const cm_model *m, int32_t B, double flops[8], doubl
       const double tiles = (double)(a.Zo / op.f16d_bz) * (a.Yo / op.f16d_by) * (a.Xo / op.f16d_bx);
       f = tiles * 128.0 * op.f16d_mbw * a.Co * (Ci * 27.0 + (op.d_w16d_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
       mult16 = 1.0;
+    } else if (op.fin) {
+      // 64-row x 128-column x 32-deep GEMM per (plane, in-plane tile): rows beyond the halo box and columns beyond 27 x Co are padding
+      f = (double)(a.Yo / op.fin_by) * (a.Xo / op.fin_bx) * a.Zo * 64.0 * 128.0 * 32.0 * 2;
+      mult16 = (p16 && op.d_wfin16) ? 1.0 : 6.0;
     } else if (op.b6d && !p16) {
       const double tiles = (double)(a.Zo / op.b6d_bz) * (a.Yo / op.b6d_by) * (a.Xo / op.b6d_bx);
       f = tiles * 32.0 * op.b6d_nw * op.b6d_mbw * a.Co * (Ci * 27.0 + (op.d_wb6d_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
