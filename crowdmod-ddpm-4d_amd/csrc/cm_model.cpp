@@ -2656,8 +2656,16 @@ int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const
     // Step 0 of every lane from the calling thread (lazy tile set-up and function attributes happen there, once);
     // the remaining steps of lane ln > 0 are enqueued by a host thread of its own, so that the lanes' launch
     // streams fill independently (one thread alternating between the streams is launch-bandwidth bound).
-    for (int ln = 0; ln < lanes; ++ln)
+    // Lane offset: lane 1 starts after lane 0 has passed a given op of its first step, so that afterwards one lane's
+    // full-resolution (issue-bound) section runs beside the other's quarter-resolution (latency-bound) section instead of both
+    // lanes marching through the same section together.  CM_LANE_OFFSET = fraction of the op list (0 = start together).
+    static const double lane_off = [] { const char *e = cm::diag_env("CM_LANE_OFFSET"); return e ? atof(e) : 0.0; }();   // (measured: 0.25 ... 0.75 all within noise of 0 -- 1.398 ... 1.414 vs 1.404 / 1.406 ms; off by default)
+    for (int ln = 0; ln < lanes; ++ln) {
+      if (ln == 0 && lanes == 2 && lane_off > 0.0 && lane_off < 1.0 && order.size() >= 2) m->mid_at = (int)(lane_off * (double)m->ops.size());
+      if (ln == 1 && lanes == 2 && lane_off > 0.0 && lane_off < 1.0 && order.size() >= 2) CM_HIP(hipStreamWaitEvent(sts[1], m->ev_half, 0));
       if (lane_steps(ln, 0, 1)) return 1;
+      m->mid_at = -1;
+    }
     // (nothing may throw across the C ABI: a worker's exception becomes its lane's error; a lane whose thread cannot be
     //  created is enqueued from the calling thread instead)
     std::vector<int> rcs((size_t)lanes, 0);
