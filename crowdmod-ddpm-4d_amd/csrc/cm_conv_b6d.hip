@@ -1,4 +1,4 @@
-// Direct 3x3x3 stride-1 convolution in fp32 arithmetic on the bf16 matrix instruction: every fp32 product is formed from
+// Direct 3x3x3 convolution (stride 1, or stride 2 = the DownSample conv, layers.py:91-97) in fp32 arithmetic on the bf16 matrix instruction: every fp32 product is formed from
 // exact three-way bf16 splits of both operands (six cross terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate -- the
 // arithmetic of DESIGN.md section 4, same as the six-term Winograd / quarter-resolution / upsample kernels).  It serves the
 // stride-1 nn.Conv3d of the full-resolution ResnetBlocks (/root/reference/models/backbones/layers.py:32,43,57,70) in
@@ -47,12 +47,13 @@ __device__ __forceinline__ float silu_d(float v) { return v * __builtin_amdgcn_r
 #ifndef CM_B6D_ABL
 #define CM_B6D_ABL 0         // compile-time ablations (experiments only; results are wrong): 1 no weight refill, 2 no halo reload,
 #endif                       // 4 no staging after chunk 0, 8 one matrix instruction of six, 16 no epilogue, 32 no A reads after tap 0
-template <int NW, int MBW, int NB>
+template <int NW, int MBW, int NB, int NLD>
 __global__ __launch_bounds__(64 * NW, 2) void conv_b6d_kernel(const ConvArgs a, const int *__restrict__ tabS,
                                                                            const int *__restrict__ tabM, int NSP, int HVP, int PY, int PZ,
                                                                            int ntp) {
   constexpr int NT = 64 * NW;
-  constexpr int NLD = 10;                        // staging items (voxel, channel quad) per thread and chunk: 4 NSP / NT <= 10
+  // NLD: staging items (voxel, channel quad) per thread and chunk, 4 NSP / NT <= NLD (10 at stride 1, 20 at stride 2, whose halo
+  // is 8 staged voxels per output voxel)
   constexpr int RW = 12;                         // LDS row: 3 terms x 4 dwords (8 bf16 of one k half)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *A = lds;                                // [2 hh][HVP][RW]
@@ -321,20 +322,28 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b6d_kernel(const ConvArgs a, 
 // Tile = bz x by x bx output voxels (divisors of the grid), rows = bz by bx <= 32 NW MBW with NW MBW row blocks; NW in {2, 4}
 // waves, MBW in {1, 2, 3} row blocks per wave.  Preference: two row blocks per wave (a weight fragment feeds two of them: the
 // matrix pipe's ceiling is 0.76-0.79 instead of 0.53-0.68, tools/ubench/b6_loop.hip), full blocks, small halo, many workgroups.
-bool conv_b6d_pick(int Z, int Y, int X, int *bz, int *by, int *bx, int *nw, int *mbw) {
+int conv_b6d_nld(int stride) { return stride == 2 ? 20 : 10; }
+
+// (Z, Y, X): the OUTPUT grid; the source grid is the same at stride 1 and (Zs, Ys, Xs) at stride 2 (pad 1: output o reads 2 o - 1 + d).
+bool conv_b6d_pick(int Z, int Y, int X, int *bz, int *by, int *bx, int *nw, int *mbw, int stride, int Zs, int Ys, int Xs) {
   double best = 0;
+  const int s = stride;
+  if (s == 1) { Zs = Z; Ys = Y; Xs = X; }
+  const int nld = conv_b6d_nld(s);
   for (int w : {2, 4})
-    for (int m = 1; m <= 2; ++m)
+    for (int m = 1; m <= (s == 2 ? 1 : 2); ++m)
       for (int z = 1; z <= Z; ++z)
         for (int y = 1; y <= Y; ++y)
           for (int x = 1; x <= X; ++x) {
             if (Z % z || Y % y || X % x) continue;
             const int rows = z * y * x, cap = 32 * w * m;
             if (rows > cap || rows <= cap - 32 * w) continue;       // every wave's LAST block at least partly filled
-            const int hv = (z + 2) * (y + 2) * (x + 2);
-            const int hreal = std::min(z + 2, Z) * std::min(y + 2, Y) * std::min(x + 2, X);
-            if (4 * hreal > 10 * 64 * w) continue;                    // staging items per thread (NLD)
-            const double eff = (double)rows / cap, halo = (double)rows / hreal;
+            const int hz = s * (z - 1) + 3, hy = s * (y - 1) + 3, hx = s * (x - 1) + 3;
+            const int hv = hz * hy * hx;
+            const int hreal = std::min(hz, Zs) * std::min(hy, Ys) * std::min(hx, Xs);
+            if (4 * hreal > nld * 64 * w) continue;                   // staging items per thread (NLD)
+            if ((size_t)(hv + 8) * 96 > 160 * 1024) continue;
+            const double eff = (double)rows / cap, halo = std::min(1.0, (double)rows * s * s * s / hreal);
             const double lds = (double)hv * 96.0;
             const double wgs = std::min(4.0, std::floor(160.0 * 1024 / lds)) * w;   // waves per CU by LDS
             const double score = eff * (0.4 + 0.6 * halo) * (m == 2 ? 1.0 : 0.8) * (wgs >= 8 ? 1.0 : 0.8) * (w == 2 ? 1.0 : 0.97);
@@ -346,7 +355,7 @@ bool conv_b6d_pick(int Z, int Y, int X, int *bz, int *by, int *bx, int *nw, int 
 // Row order of a tile: the 16 rows that one service group of ds_read_b128 reads ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a
 // 32-row block) must sit on 16 different 48-byte slots mod 16 rows.  Try the six nesting orders of (z, y, x) and keep the one with
 // the fewest conflicts (0 for the reference grids' 8 x 4 x 4 tile: y outermost).  `rowvox[m]` = (z, y, x) packed as z<<16|y<<8|x.
-static int b6d_row_order(int bz, int by, int bx, int PY, int PZ, std::vector<int> &rowvox) {
+static int b6d_row_order(int bz, int by, int bx, int PY, int PZ, int stride, std::vector<int> &rowvox) {
   static const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
   const int dim[3] = {bz, by, bx};
   const int rows = bz * by * bx;
@@ -370,7 +379,7 @@ static int b6d_row_order(int bz, int by, int bx, int PY, int PZ, std::vector<int
           const bool g0 = rr < 4 || (rr >= 12 && rr < 16) || (rr >= 20 && rr < 28);
           if (g0 != (g == 0) || blk * 32 + rr >= rows) continue;
           const int v = cand[(size_t)(blk * 32 + rr)];
-          const int h = (v >> 16) * PZ + ((v >> 8) & 255) * PY + (v & 255);
+          const int h = stride * ((v >> 16) * PZ + ((v >> 8) & 255) * PY + (v & 255));
           conf += cnt[h & 15]++;
         }
       }
@@ -382,13 +391,15 @@ static int b6d_row_order(int bz, int by, int bx, int PY, int PZ, std::vector<int
 struct B6dTabs { int *tS = nullptr, *tM = nullptr; int NSP = 0, HVP = 0, PY = 0, PZ = 0, ntp = 0, conflicts = 0; };
 // host-only table builder (also used by the self-test)
 void conv_b6d_tables(int Z, int Y, int X, int bz, int by, int bx, int nw, int mbw, std::vector<int> &tS, std::vector<int> &tM,
-                     int *NSP, int *HVP, int *PY_, int *PZ_, int *ntp_, int *conflicts) {
-  const int HZ = bz + 2, HY = by + 2, HX = bx + 2, HV = HZ * HY * HX;
+                     int *NSP, int *HVP, int *PY_, int *PZ_, int *ntp_, int *conflicts, int stride, int Zs, int Ys, int Xs) {
+  const int s = stride;
+  if (s == 1) { Zs = Z; Ys = Y; Xs = X; }
+  const int HZ = s * (bz - 1) + 3, HY = s * (by - 1) + 3, HX = s * (bx - 1) + 3, HV = HZ * HY * HX;
   const int PY = HX, PZ = HY * HX;
   const int ntz = Z / bz, nty = Y / by, ntx = X / bx, ntp = ntz * nty * ntx;
   const int rows = bz * by * bx, MR = 32 * nw * mbw;
   std::vector<int> rowvox;
-  const int conf = b6d_row_order(bz, by, bx, PY, PZ, rowvox);
+  const int conf = b6d_row_order(bz, by, bx, PY, PZ, s, rowvox);
   int hvp = HV;
   while ((hvp & 7) != 4) ++hvp;
   // staging lists: real voxels only; NSP = longest list
@@ -398,12 +409,12 @@ void conv_b6d_tables(int Z, int Y, int X, int bz, int by, int bx, int nw, int mb
     for (int ty = 0; ty < nty; ++ty)
       for (int tx = 0; tx < ntx; ++tx) {
         const int p = (tz * nty + ty) * ntx + tx;
-        const int z0 = tz * bz, y0 = ty * by, x0 = tx * bx;
+        const int z0 = s * tz * bz, y0 = s * ty * by, x0 = s * tx * bx;
         for (int h = 0; h < HV; ++h) {
           const int hz = h / (HY * HX), rem = h % (HY * HX), hy = rem / HX, hx = rem % HX;
           const int cz = z0 - 1 + hz, cy = y0 - 1 + hy, cx = x0 - 1 + hx;
-          if (cz >= 0 && cz < Z && cy >= 0 && cy < Y && cx >= 0 && cx < X) {
-            lists[(size_t)p].push_back((cz * Y + cy) * X + cx);
+          if (cz >= 0 && cz < Zs && cy >= 0 && cy < Ys && cx >= 0 && cx < Xs) {
+            lists[(size_t)p].push_back((cz * Ys + cy) * Xs + cx);
             lists[(size_t)p].push_back(h);
           }
         }
@@ -422,7 +433,7 @@ void conv_b6d_tables(int Z, int Y, int X, int bz, int by, int bx, int nw, int mb
       int hidx = 0, ov = -1;
       if (m < rows) {
         const int v = rowvox[(size_t)m], z = v >> 16, y = (v >> 8) & 255, x = v & 255;
-        hidx = z * PZ + y * PY + x;                // halo row of tap (0, 0, 0) for this output voxel
+        hidx = s * (z * PZ + y * PY + x);          // halo row of tap (0, 0, 0) for this output voxel
         ov = ((tz * bz + z) * Y + (ty * by + y)) * X + (tx * bx + x);
       }
       tM[((size_t)p * MR + m) * 2] = hidx;
@@ -435,16 +446,17 @@ void conv_b6d_tables(int Z, int Y, int X, int bz, int by, int bx, int nw, int mb
 
 static hipError_t b6d_tabs_get(const ConvArgs &a, int nw, int mbw, B6dTabs *out) {
   static std::mutex mu;
-  static std::map<std::tuple<int, int, int, int, int, int, int, int, int>, B6dTabs> cache;
+  static std::map<std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, int>, B6dTabs> cache;
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const auto key = std::make_tuple(dev, a.Zo, a.Yo, a.Xo, a.bz, a.by, a.bx, nw, mbw);
+  const auto key = std::make_tuple(dev, a.Zo, a.Yo, a.Xo, a.bz, a.by, a.bx, nw, mbw, a.stride, a.Zs, a.Ys, a.Xs);
   std::lock_guard<std::mutex> lk(mu);
   auto it = cache.find(key);
   if (it == cache.end()) {
     std::vector<int> tS, tM;
     B6dTabs t;
-    conv_b6d_tables(a.Zo, a.Yo, a.Xo, a.bz, a.by, a.bx, nw, mbw, tS, tM, &t.NSP, &t.HVP, &t.PY, &t.PZ, &t.ntp, &t.conflicts);
+    conv_b6d_tables(a.Zo, a.Yo, a.Xo, a.bz, a.by, a.bx, nw, mbw, tS, tM, &t.NSP, &t.HVP, &t.PY, &t.PZ, &t.ntp, &t.conflicts, a.stride, a.Zs, a.Ys,
+                    a.Xs);
     hipError_t e = hipMalloc((void **)&t.tS, tS.size() * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&t.tM, tM.size() * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(t.tS, tS.data(), tS.size() * sizeof(int), hipMemcpyHostToDevice);
@@ -457,14 +469,17 @@ static hipError_t b6d_tabs_get(const ConvArgs &a, int nw, int mbw, B6dTabs *out)
 }
 
 bool conv_b6d_ok(const ConvArgs &a, int nw, int mbw) {
-  if (!(a.ntaps == 27 && a.stride == 1 && !a.par && !a.ups && a.C0 % 16 == 0 && a.C1 % 16 == 0 && a.Co % 32 == 0 && a.Zs == a.Zo &&
-        a.Ys == a.Yo && a.Xs == a.Xo && (nw == 2 || nw == 4) && mbw >= 1 && mbw <= 2 && a.bz > 0 && a.by > 0 && a.bx > 0 &&
+  const int s = a.stride;
+  if (!(a.ntaps == 27 && (s == 1 || s == 2) && !a.par && !a.ups && a.C0 % 16 == 0 && a.C1 % 16 == 0 && a.Co % 32 == 0 &&
+        a.Zo == (a.Zs - 1) / s + 1 && a.Yo == (a.Ys - 1) / s + 1 && a.Xo == (a.Xs - 1) / s + 1 && (nw == 2 || nw == 4) && mbw >= 1 &&
+        mbw <= (s == 2 ? 1 : 2) && a.bz > 0 && a.by > 0 && a.bx > 0 &&
         a.Zo % a.bz == 0 && a.Yo % a.by == 0 && a.Xo % a.bx == 0 && a.bz * a.by * a.bx <= 32 * nw * mbw &&
-        (!a.s2w || (a.s2C0 % 16 == 0 && a.s2C1 % 16 == 0))))
+        (!a.s2w || (s == 1 && a.s2C0 % 16 == 0 && a.s2C1 % 16 == 0))))
     return false;
-  const int hreal = std::min(a.bz + 2, a.Zo) * std::min(a.by + 2, a.Yo) * std::min(a.bx + 2, a.Xo);
-  const int hv = (a.bz + 2) * (a.by + 2) * (a.bx + 2);
-  return 4 * hreal <= 10 * 64 * nw && (size_t)(hv + 8) * 96 <= 160 * 1024;
+  const int hz = s * (a.bz - 1) + 3, hy = s * (a.by - 1) + 3, hx = s * (a.bx - 1) + 3;
+  const int hreal = std::min(hz, a.Zs) * std::min(hy, a.Ys) * std::min(hx, a.Xs);
+  const int hv = hz * hy * hx;
+  return 4 * hreal <= conv_b6d_nld(s) * 64 * nw && (size_t)(hv + 8) * 96 <= 160 * 1024;
 }
 
 // column blocks per workgroup (fragment packing): one -- two spill the 2-row-block form's registers
@@ -483,20 +498,21 @@ hipError_t launch_conv_b6d(const ConvArgs &a_in, int nw, int mbw, hipStream_t st
   const int nb = conv_b6d_nb(a.Co);
   const size_t lds = (size_t)tb.HVP * 2 * 12 * sizeof(float);
   const dim3 grid((unsigned)(a.B * tb.ntp), (unsigned)(a.Co / (32 * nb)));
-#define CM_B6D_GO(W, M, N)                                                                          \
-  if (nw == W && mbw == M && nb == N) {                                                             \
+  const int nld = conv_b6d_nld(a.stride);
+#define CM_B6D_GO(W, M, N, L)                                                                       \
+  if (nw == W && mbw == M && nb == N && nld == L) {                                                 \
     static bool attr_set[64] = {false};                                                             \
     int dev = 0;                                                                                    \
     (void)hipGetDevice(&dev);                                                                       \
     if (!attr_set[dev & 63]) {                                                                      \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_b6d_kernel<W, M, N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_b6d_kernel<W, M, N, L>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       if (e != hipSuccess) return e;                                                                \
       attr_set[dev & 63] = true;                                                                    \
     }                                                                                               \
-    hipLaunchKernelGGL((conv_b6d_kernel<W, M, N>), grid, dim3(64 * W), lds, st, a, tb.tS, tb.tM, tb.NSP, tb.HVP, tb.PY, tb.PZ, tb.ntp); \
+    hipLaunchKernelGGL((conv_b6d_kernel<W, M, N, L>), grid, dim3(64 * W), lds, st, a, tb.tS, tb.tM, tb.NSP, tb.HVP, tb.PY, tb.PZ, tb.ntp); \
     return hipGetLastError();                                                                       \
   }
-  CM_B6D_GO(2, 1, 1) CM_B6D_GO(2, 2, 1) CM_B6D_GO(4, 1, 1) CM_B6D_GO(4, 2, 1)
+  CM_B6D_GO(2, 1, 1, 10) CM_B6D_GO(2, 2, 1, 10) CM_B6D_GO(4, 1, 1, 10) CM_B6D_GO(4, 2, 1, 10) CM_B6D_GO(2, 1, 1, 20) CM_B6D_GO(4, 1, 1, 20)
 #undef CM_B6D_GO
   return hipErrorInvalidValue;
 }

@@ -459,7 +459,10 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
     // split fragments [n tile][wave][step][tap 9][dz][term][lane] 16 B (pack_qr_b6)
     const int ngw = nsteps * 9;
     const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.wq6) + ((size_t)(nt * 8 + wave) * ngw) * 9 * 64 + lane;
-    constexpr int RD = 1;                           // (must divide 9: a slot is tap % RD in every step; 3 would be 108 registers)
+#ifndef CM_QR2_RD
+#define CM_QR2_RD 1
+#endif
+    constexpr int RD = MBP == 1 ? CM_QR2_RD : 1;    // (must divide 9: a slot is tap % RD in every step; 3 is 108 registers)
     f32x4 bw[RD][3][3];
 #pragma unroll
     for (int t = 0; t < RD; ++t)

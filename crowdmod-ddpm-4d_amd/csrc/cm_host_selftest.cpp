@@ -303,6 +303,50 @@ void test_round3_packers() {
       for (int v = 0; v < V; ++v) EXPECT(owned[(size_t)v] == 1);
     }
   }
+  // the same kernel at stride 2 (the DownSample convs of the reference configs, source grid -> output grid): every tap of every
+  // output voxel reads the LDS row that holds exactly source voxel 2 o - 1 + d, or a never-written (zero) row when that is padding
+  {
+    const int sgrids[][3] = {{8, 12, 36}, {4, 6, 18}, {8, 28, 24}, {4, 14, 12}, {8, 24, 72}, {4, 12, 36}, {16, 12, 36}, {8, 12, 20}, {4, 6, 10}, {5, 7, 9}};
+    for (auto &g : sgrids) {
+      const int Zo = (g[0] - 1) / 2 + 1, Yo = (g[1] - 1) / 2 + 1, Xo = (g[2] - 1) / 2 + 1;
+      int bz = 0, by = 0, bx = 0, nw = 0, mbw = 0;
+      EXPECT(cm::conv_b6d_pick(Zo, Yo, Xo, &bz, &by, &bx, &nw, &mbw, 2, g[0], g[1], g[2]));
+      cm::ConvArgs a{};
+      a.ntaps = 27; a.stride = 2; a.C0 = 32; a.Co = 32; a.Zs = g[0]; a.Ys = g[1]; a.Xs = g[2]; a.Zo = Zo; a.Yo = Yo; a.Xo = Xo; a.bz = bz; a.by = by; a.bx = bx;
+      EXPECT(cm::conv_b6d_ok(a, nw, mbw) && cm::conv_b6d_slots(a, nw, mbw) <= MAX_SLOTS && mbw == 1);
+      std::vector<int> tS, tM;
+      int NSP = 0, HVP = 0, PY = 0, PZ = 0, ntp = 0, conf = -1;
+      cm::conv_b6d_tables(Zo, Yo, Xo, bz, by, bx, nw, mbw, tS, tM, &NSP, &HVP, &PY, &PZ, &ntp, &conf, 2, g[0], g[1], g[2]);
+      const int HV = (2 * bz + 1) * (2 * by + 1) * (2 * bx + 1), MR = 32 * nw * mbw, Vo = Zo * Yo * Xo, Vs = g[0] * g[1] * g[2];
+      EXPECT(ntp == (Zo / bz) * (Yo / by) * (Xo / bx) && HVP >= HV && (HVP & 7) == 4 && 4 * NSP <= cm::conv_b6d_nld(2) * 64 * nw);
+      std::vector<int> owned((size_t)Vo, 0);
+      for (int p = 0; p < ntp; ++p) {
+        std::vector<int> rowsrc((size_t)HV, -1);
+        for (int i = 0; i < NSP; ++i) {
+          const int src = tS[((size_t)p * NSP + i) * 2], row = tS[((size_t)p * NSP + i) * 2 + 1];
+          if (src < 0) continue;
+          EXPECT(src < Vs && row >= 0 && row < HV && rowsrc[(size_t)row] < 0);
+          rowsrc[(size_t)row] = src;
+        }
+        for (int m2 = 0; m2 < MR; ++m2) {
+          const int hidx = tM[((size_t)p * MR + m2) * 2], ov = tM[((size_t)p * MR + m2) * 2 + 1];
+          EXPECT(hidx >= 0 && hidx + 2 * PZ + 2 * PY + 2 < HVP);
+          if (ov < 0) continue;
+          EXPECT(ov < Vo);
+          owned[(size_t)ov] += 1;
+          const int oz = ov / (Yo * Xo), oy = (ov / Xo) % Yo, ox = ov % Xo;
+          for (int t = 0; t < 27; ++t) {
+            const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+            const int cz = 2 * oz - 1 + dz, cy = 2 * oy - 1 + dy, cx = 2 * ox - 1 + dx;
+            const bool real = cz >= 0 && cz < g[0] && cy >= 0 && cy < g[1] && cx >= 0 && cx < g[2];
+            const int row = hidx + dz * PZ + dy * PY + dx;
+            EXPECT(row < HV && rowsrc[(size_t)row] == (real ? (cz * g[1] + cy) * g[2] + cx : -1));
+          }
+        }
+      }
+      for (int v = 0; v < Vo; ++v) EXPECT(owned[(size_t)v] == 1);
+    }
+  }
   // stage-once upsample kernel: a source tile for every upsample source grid of the reference configs (ATC, CR-120, 24x72),
   // planes tiles where a plane fits one row block; the launcher's own feasibility test agrees with the picker
   const int srcs[][3] = {{2, 3, 9}, {4, 6, 18}, {2, 7, 6}, {4, 14, 12}, {2, 6, 18}, {4, 12, 36}};

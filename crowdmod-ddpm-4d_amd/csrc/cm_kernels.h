@@ -355,14 +355,15 @@ hipError_t launch_conv_f16d(const ConvArgs &a, int mbw, hipStream_t st);
 // a.bz/by/bx = output box (divides the grid), nw = waves per workgroup (2 / 4), mbw = 32-row blocks per wave;
 // a.wfrag: [Co/(32 NB)][Ci/16][27][NB][3 terms][64 lanes][8 bf16] (pack_b6d), a.s2w: [Co/(32 NB)][Cs/16][NB][3][64][8], NB =
 // conv_b6d_nb(Co); statistics slots per sample: conv_b6d_slots.
-bool conv_b6d_pick(int Z, int Y, int X, int *bz, int *by, int *bx, int *nw, int *mbw);
+bool conv_b6d_pick(int Z, int Y, int X, int *bz, int *by, int *bx, int *nw, int *mbw, int stride = 1, int Zs = 0, int Ys = 0, int Xs = 0);
 bool conv_b6d_ok(const ConvArgs &a, int nw, int mbw);
 int conv_b6d_slots(const ConvArgs &a, int nw, int mbw);
 int conv_b6d_nb(int Co);
 hipError_t launch_conv_b6d(const ConvArgs &a, int nw, int mbw, hipStream_t st);
 // host-side geometry tables of one (grid, tile) pair (cm_conv_b6d.hip; also driven by the sanitizer self-test)
 void conv_b6d_tables(int Z, int Y, int X, int bz, int by, int bx, int nw, int mbw, std::vector<int> &tS, std::vector<int> &tM,
-                     int *NSP, int *HVP, int *PY, int *PZ, int *ntp, int *conflicts);
+                     int *NSP, int *HVP, int *PY, int *PZ, int *ntp, int *conflicts, int stride = 1, int Zs = 0, int Ys = 0, int Xs = 0);
+int conv_b6d_nld(int stride);   // staging items per thread the kernel instance of this stride holds
 // split fragments from the layer's fp32 weights in the REFERENCE layout [Co][Ci][kH][kW][kL] (or [Co][Ci], taps = 1), e.g. after an optimizer step
 hipError_t launch_b6d_repack(const float *w, float *w6, int Co, int Ci, int taps, int NB, hipStream_t st);
 

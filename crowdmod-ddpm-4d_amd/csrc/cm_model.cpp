@@ -127,6 +127,7 @@ struct Op {
   bool dbg_raw = false;     // cm_debug_conv_io: the whole-sample quarter-resolution kernel without its GroupNorm (raw sources)
   bool b6d = false;         // fp32 plan: direct six-term kernel (cm_conv_b6d.hip) instead of the six-term Winograd one (inference forward)
   int b6d_bz = 0, b6d_by = 0, b6d_bx = 0, b6d_nw = 0, b6d_mbw = 0;
+  bool b6s2 = false;        // fp32 plan: the stride-2 DownSample conv on the same kernel (tile fields above)
   float *d_wb6d = nullptr, *d_wb6d_skip = nullptr;
   bool qr = false;          // whole-sample kernel of the lowest resolution (cm_conv_qr.hip), inference plan
   float *d_wqr = nullptr, *d_wqr_skip = nullptr;
@@ -1093,6 +1094,23 @@ int add_conv(cm_model *m, const ConvSpec &s) {
       op.b6d = true;
     }
   }
+  // fp32 plan: the DownSample conv (3x3x3, stride 2, raw input: layers.py:91-97) on the direct six-term kernel -- one staging pass
+  // and the split per staged element, no K split / second pass at quarter resolution.  OPT-IN (CM_DIAG=1 CM_B6S2=1): measured
+  // SLOWER than the generic kernel on the ATC grid (32.2 vs 31.5 us at half resolution, 46.7 vs 18.7 + 7.0 us at quarter
+  // resolution; step 1.402 vs 1.380 ms): with one row block per wave the kernel waits on its weight fragments (3 taps of
+  // read-ahead = 576 matrix cycles, less than the L2 latency under load) and an 8-voxel halo per output voxel is staged per chunk
+  if (s.ntaps == 27 && s.stride == 2 && !s.ups && !parity && !s.gn && !s.temb && !s.resid && !s.skip0 && m->precision != CM_PRECISION_F16 &&
+      Ci_ref == Ci_pad && a.C0 % 16 == 0 && a.C1 % 16 == 0 && s.Co % 32 == 0 && s.Co == s.out->C && cm::diag_env("CM_B6S2") &&
+      cm::conv_b6d_pick(s.out->Z, s.out->Y, s.out->X, &op.b6d_bz, &op.b6d_by, &op.b6d_bx, &op.b6d_nw, &op.b6d_mbw, 2, s.s0->Z, s.s0->Y, s.s0->X)) {
+    if (const char *t = cm::diag_env("CM_B6S2_TILE")) {      // "bz,by,bx,nw": A/B of tile shapes
+      int z = 0, y = 0, x = 0, w = 0;
+      if (sscanf(t, "%d,%d,%d,%d", &z, &y, &x, &w) == 4 && s.out->Z % z == 0 && s.out->Y % y == 0 && s.out->X % x == 0 && z * y * x <= 32 * w) {
+        op.b6d_bz = z; op.b6d_by = y; op.b6d_bx = x; op.b6d_nw = w; op.b6d_mbw = 1;
+      }
+    }
+    if (upload(m, pack_b6d(wi.data(), s.Co, Ci_ref, 27, cm::conv_b6d_nb(s.Co)), &op.d_wb6d)) return 1;
+    op.b6s2 = true;
+  }
   // the UNet's first conv (C <= 8 data channels -> base): dedicated kernel, whole weight set in registers
   if (s.s0 == m->x8_act && s.ntaps == 27 && s.stride == 1 && !s.ups && !s.gn && !s.temb && !s.resid && !s.s1 &&
       s.Co % 32 == 0 && Ci_ref <= 8 && !cm::diag_env("CM_NO_FIRSTK")) {
@@ -1695,15 +1713,21 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   }
   // ---- which kernel will run (needed up front: only some kernels speak the accumulator statistics of round 4) -------------------
   static const bool no_train_b6 = cm::diag_env("CM_NO_TRAIN_B6") != nullptr;
-  const bool take_ups = op.ks <= 1 && op.ups && (op.d_wups16 || !(op.d_wfrag16 && !m->train_fwd));
-  const bool take_f16d = op.ks <= 1 && !take_ups && op.wino && op.f16d && !m->train_fwd;
-  const bool take_b6d = op.ks <= 1 && !take_ups && !take_f16d && op.wino && op.b6d && !m->train_fwd && m->precision != CM_PRECISION_F16;
-  const bool take_wino = op.ks <= 1 && !take_ups && !take_f16d && !take_b6d && op.wino;
+  cm::ConvArgs s2a = ca;
+  s2a.bz = op.b6d_bz; s2a.by = op.b6d_by; s2a.bx = op.b6d_bx;
+  // (the training forward as well: exact splits, fp32 accumulate; its fragments follow every optimizer step)
+  const bool take_b6s2 = op.b6s2 && !(m->train_fwd && no_train_b6) && m->precision != CM_PRECISION_F16 && !ca.h16 && !ca.pm &&
+                         cm::conv_b6d_ok(s2a, op.b6d_nw, op.b6d_mbw);
+  const int ks = take_b6s2 ? 1 : op.ks;            // (the direct stride-2 kernel replaces the K split)
+  const bool take_ups = ks <= 1 && op.ups && (op.d_wups16 || !(op.d_wfrag16 && !m->train_fwd));
+  const bool take_f16d = ks <= 1 && !take_ups && op.wino && op.f16d && !m->train_fwd;
+  const bool take_b6d = take_b6s2 || (ks <= 1 && !take_ups && !take_f16d && op.wino && op.b6d && !m->train_fwd && m->precision != CM_PRECISION_F16);
+  const bool take_wino = ks <= 1 && !take_ups && !take_f16d && !take_b6d && op.wino;
   // The slot count of the output tensor is written ONCE per launch with the count of the kernel that runs: the batch lanes
   // enqueue from two host threads, and the other lane's gn_finalize reads it -- a generic count first and the upsample /
   // direct kernel's own count afterwards left a window in which that reader saw the wrong number of slots (a rare wrong
   // statistic: the one-off failure of the two-lane bit-identity test in round 4).  All lanes write the same value.
-  if (op.stat_act && op.ks <= 1 && !take_ups && !take_f16d && !take_b6d) op.stat_act->nslots = ns;
+  if (op.stat_act && ks <= 1 && !take_ups && !take_f16d && !take_b6d) op.stat_act->nslots = ns;
   const bool wino_f16 = take_wino && op.d_wwino16 && !m->train_fwd;     // reduced-precision plan: f16 operands in the inference forward
   // two-tile layers / the full-resolution tile, fp32 plan: six-term bf16 products (the training forward as well: exact splits, fp32
   // accumulate; its fragments follow every optimizer step)
@@ -1711,8 +1735,8 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
                        cm::conv_wino_b6_ok(ca.bz, ca.by, ca.bx, ca.Co, ca.Zo);
   if (ca.h16) {
     // only these kernels read / write f16 tensors; anything else here would misread them silently
-    const bool ok16 = take_f16d || (take_ups && op.d_wups16 && !(ca.h16 & ~5)) || (op.first_k && !(ca.h16 & ~4) && op.ks <= 1 && !take_ups && !op.wino) ||
-                      (op.small_n && !(ca.h16 & ~3) && op.ks <= 1 && !take_ups && !op.wino && !op.first_k);
+    const bool ok16 = take_f16d || (take_ups && op.d_wups16 && !(ca.h16 & ~5)) || (op.first_k && !(ca.h16 & ~4) && ks <= 1 && !take_ups && !op.wino) ||
+                      (op.small_n && !(ca.h16 & ~3) && ks <= 1 && !take_ups && !op.wino && !op.first_k);
     if (!ok16) return fail("conv %s: f16 tensors (mask %d) reach a kernel without f16 tensor support", op.label.c_str(), ca.h16);
   }
   // consumer side: the GroupNorm of the input comes from the producers' accumulator rows -- finalised inside the six-term
@@ -1758,8 +1782,8 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     ca.stat_part = nullptr; ca.stat_cnt = nullptr;
     m->astat_clean[slab & 3].B = 0;
   };
-  if (use_astat && op.ks > 1) return fail("conv %s: a K-split layer cannot feed accumulator statistics", op.label.c_str());
-  if (op.ks > 1) {
+  if (use_astat && ks > 1) return fail("conv %s: a K-split layer cannot feed accumulator statistics", op.label.c_str());
+  if (ks > 1) {
     cm::ConvArgs ka = ca;
     const int V = op.out_act->V();
     float *scratch = m->ks_scratch + (size_t)slab * m->ks_scratch_floats;
@@ -1945,7 +1969,9 @@ int run_ops(cm_model *m, int B, hipStream_t st, int b0 = 0, int slab = 0) {
         op.fin_skipped[slab & 3] = false;
         // (<= 16 slots: measured -0.7 % on the ATC step, -1.6 % on the 24x72 f16 plan; HERMES-CR-120's half resolution has 24 slots
         //  per tensor and up to 192 channels -- there the merge in 256 workgroups cost more than the launch, +0.5 %)
-        if (op.from_slots && !m->train_fwd && op.g0->nslots <= 16 && (!op.g1 || op.g1->nslots <= 16) &&
+        static const int few_sc = cm::diag_env("CM_FEW_SC") ? atoi(cm::diag_env("CM_FEW_SC")) : 0;   // (slots x channels bound, experiments)
+        const auto few = [](const Act *t) { return t->nslots <= 16 || t->nslots * t->C <= few_sc; };
+        if (op.from_slots && !m->train_fwd && few(op.g0) && (!op.g1 || few(op.g1)) &&
             (!op.g1 || op.g1->V() == op.g0->V())) {
           op.fin_skipped[slab & 3] = true;            // few slots: the consuming Winograd conv merges them in its prologue (run_conv)
           break;
@@ -2893,7 +2919,7 @@ int cm_debug_conv_io(cm_model *m, int32_t index, int32_t mode, const float *h_in
   tmp.d_s2w = nullptr; tmp.d_wqr_skip = nullptr; tmp.skip_if_fused = false; tmp.dbg_raw = true; tmp.pm_off = -1;
   if (!tmp.qr) tmp.gn_op = -1;
   if (tmp.stat_act && tmp.stat_act->aoff >= 0) tmp.stat_act = nullptr;      // (no additions to the accumulator rows of the plan)
-  if (mode == 1) { tmp.d_wwino_b6 = nullptr; tmp.d_wqr_b6 = nullptr; tmp.d_wups_b6 = nullptr; tmp.b6d = false; }
+  if (mode == 1) { tmp.d_wwino_b6 = nullptr; tmp.d_wqr_b6 = nullptr; tmp.d_wups_b6 = nullptr; tmp.b6d = false; tmp.b6s2 = false; }
   const int ns_keep = op.stat_act ? op.stat_act->nslots : 0;
   const int rc = run_conv(m, tmp, B, st, 0, 0);
   const hipError_t e = hipStreamSynchronize(st);
@@ -2992,7 +3018,7 @@ static int exec_flops_split(const cm_model *m, int32_t B, double flops[8], doubl
       // 64-row x 128-column x 32-deep GEMM per (plane, in-plane tile): rows beyond the halo box and columns beyond 27 x Co are padding
       f = (double)(a.Yo / op.fin_by) * (a.Xo / op.fin_bx) * a.Zo * 64.0 * 128.0 * 32.0 * 2;
       mult16 = (p16 && op.d_wfin16) ? 1.0 : 6.0;
-    } else if (op.b6d && !p16) {
+    } else if ((op.b6d || op.b6s2) && !p16) {
       const double tiles = (double)(a.Zo / op.b6d_bz) * (a.Yo / op.b6d_by) * (a.Xo / op.b6d_bx);
       f = tiles * 32.0 * op.b6d_nw * op.b6d_mbw * a.Co * (Ci * 27.0 + (op.d_wb6d_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
       mult16 = 6.0;
