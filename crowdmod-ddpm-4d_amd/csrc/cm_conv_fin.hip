@@ -41,8 +41,10 @@ constexpr int FIN_ROWS = 64;                     // halo voxels of a plane tile 
 constexpr int FIN_PCOLS = 132;                   // P row stride in floats (128 columns + 4: 16-byte gathers of a row group stay apart)
 
 // wfin: [nb 4][k step 2][term NTM][lane 64] 16 B, column n = 32 nb + lane % 32 = 4 t + co, k = 16 ks + 8 (lane / 32) + j
-template <bool F16>
+template <int MODE>                                // 0: six bf16 cross terms, 1: f16 operands, 2: three bf16 cross terms (relaxed plan), 3: three f16 cross terms (h2)
 __global__ __launch_bounds__(256, 2) void conv_fin_kernel(const ConvArgs a, const float *__restrict__ wfin, int ntx) {
+  constexpr bool F16 = MODE == 1, H2 = MODE == 3;
+  constexpr int U0 = MODE >= 2 ? 3 : 0, NTW = MODE >= 2 ? 2 : 3;
   constexpr int NTM = F16 ? 1 : 3;
   constexpr int RW = F16 ? 4 : 12;               // LDS dwords per (k half, row): terms x 4
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -113,9 +115,10 @@ __global__ __launch_bounds__(256, 2) void conv_fin_kernel(const ConvArgs a, cons
         *reinterpret_cast<f16x4 *>(dst) = hv4;
       } else {
         cm_u32x2_t t3[3];
-        cm_split3_bf16(w, t3);
+        if constexpr (H2) cm_split2_f16(w, t3);
+        else cm_split3_bf16<NTW>(w, t3);
 #pragma unroll
-        for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<cm_u32x2_t *>(dst + 4 * tm) = t3[tm];
+        for (int tm = 0; tm < NTW; ++tm) *reinterpret_cast<cm_u32x2_t *>(dst + 4 * tm) = t3[tm];
       }
     }
   };
@@ -169,17 +172,23 @@ __global__ __launch_bounds__(256, 2) void conv_fin_kernel(const ConvArgs a, cons
 #pragma unroll
           for (int tm = 0; tm < 3; ++tm) af[tm] = *reinterpret_cast<const f32x4 *>(ap + 4 * tm);
 #pragma unroll
-          for (int u = 0; u < 6; ++u)
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw[ks][TB[u]]), __builtin_bit_cast(bf16x8, af[TA[u]]), acc[j], 0, 0, 0);
+          for (int u = U0; u < 6; ++u) {
+            if constexpr (H2)
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bw[ks][TB[u]]), __builtin_bit_cast(f16x8, af[TA[u]]), acc[j], 0, 0, 0);
+            else
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw[ks][TB[u]]), __builtin_bit_cast(bf16x8, af[TA[u]]), acc[j], 0, 0, 0);
+          }
         }
       }
     // lane (r, hh), registers 4 g .. 4 g + 3 of block j: voxel row 32 j + r, columns 4 (8 wave + 2 g + hh) + {0 .. 3} = tap 8 wave + 2 g + hh
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4 *>(P + (size_t)(32 * j + r) * FIN_PCOLS + 4 * (8 * wave + 2 * g + hh)) =
-            f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+      for (int g = 0; g < 4; ++g) {
+        f32x4 pv = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+        if constexpr (H2) pv = pv * a.h2_oscale;   // (weights were packed as w * 2^k)
+        *reinterpret_cast<f32x4 *>(P + (size_t)(32 * j + r) * FIN_PCOLS + 4 * (8 * wave + 2 * g + hh)) = pv;
+      }
     __syncthreads();                              // P complete; every wave has read A
     // ---- the next plane's image (A is free) beside this plane's gathers (P) -------------------------------------------------
     if (z + 1 < Z) {
@@ -243,25 +252,30 @@ size_t conv_fin_lds(bool f16) {
   return ((size_t)2 * 2 * FIN_ROWS * (f16 ? 4 : 12) + (size_t)FIN_ROWS * FIN_PCOLS + 3 * 64 * 4) * sizeof(float);
 }
 
-hipError_t launch_conv_fin(const ConvArgs &a_in, const float *wfin, bool f16, hipStream_t st) {
+// mode 0: six-term products (fragments of launch_fin_pack(f16 = false)), 1: f16 operands, 2: three of the six terms on the mode-0 fragments
+hipError_t launch_conv_fin(const ConvArgs &a_in, const float *wfin, int mode, hipStream_t st) {
   ConvArgs a = a_in;
   a.dbg = conv_dbg_flags();
-  if (!conv_fin_ok(a)) return hipErrorInvalidValue;
+  if (!conv_fin_ok(a) || mode < 0 || mode > 3) return hipErrorInvalidValue;
   const int nty = a.Yo / a.by, ntx = a.Xo / a.bx;
   a.nty = nty;
   const dim3 grid((unsigned)(a.B * nty * ntx));
-  const size_t lds = conv_fin_lds(f16);
-  static bool attr_set[64][2] = {{false}};
+  const size_t lds = conv_fin_lds(mode == 1);
+  static bool attr_set[64][4] = {{false}};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (!attr_set[dev & 63][f16 ? 1 : 0]) {
-    hipError_t e = f16 ? hipFuncSetAttribute(reinterpret_cast<const void *>(conv_fin_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                       : hipFuncSetAttribute(reinterpret_cast<const void *>(conv_fin_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const void *fn = mode == 1 ? reinterpret_cast<const void *>(conv_fin_kernel<1>)
+                 : mode == 2 ? reinterpret_cast<const void *>(conv_fin_kernel<2>)
+                 : mode == 3 ? reinterpret_cast<const void *>(conv_fin_kernel<3>) : reinterpret_cast<const void *>(conv_fin_kernel<0>);
+  if (!attr_set[dev & 63][mode]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set[dev & 63][f16 ? 1 : 0] = true;
+    attr_set[dev & 63][mode] = true;
   }
-  if (f16) hipLaunchKernelGGL(conv_fin_kernel<true>, grid, dim3(256), lds, st, a, wfin, ntx);
-  else hipLaunchKernelGGL(conv_fin_kernel<false>, grid, dim3(256), lds, st, a, wfin, ntx);
+  if (mode == 1) hipLaunchKernelGGL(conv_fin_kernel<1>, grid, dim3(256), lds, st, a, wfin, ntx);
+  else if (mode == 2) hipLaunchKernelGGL(conv_fin_kernel<2>, grid, dim3(256), lds, st, a, wfin, ntx);
+  else if (mode == 3) hipLaunchKernelGGL(conv_fin_kernel<3>, grid, dim3(256), lds, st, a, wfin, ntx);
+  else hipLaunchKernelGGL(conv_fin_kernel<0>, grid, dim3(256), lds, st, a, wfin, ntx);
   return hipGetLastError();
 }
 
@@ -269,7 +283,7 @@ hipError_t launch_conv_fin(const ConvArgs &a_in, const float *wfin, bool f16, hi
 // [dy][dx][dz]): [nb 4][k step 2][term][lane 64][8 x 16 bit]; column n = 32 nb + lane % 32 = 4 t + co (t = (dz * 3 + dy) * 3 + dx; columns
 // >= 108 and co >= Co are zero), k = 16 ks + 8 (lane / 32) + j.  f16 = 0: three bf16 terms (exact split), 1: one f16 term.
 // One thread per (nb, ks, lane, j); run at load time and after every optimizer step (the same kernel: one definition).
-__global__ __launch_bounds__(256) void fin_pack_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Co, int f16) {
+__global__ __launch_bounds__(256) void fin_pack_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Co, int f16, float wscale) {
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= 4 * 2 * 64 * 8) return;
   const int j = o & 7, lane = (o >> 3) & 63, ks = (o >> 9) & 1, nb = o >> 10;
@@ -279,9 +293,16 @@ __global__ __launch_bounds__(256) void fin_pack_kernel(const float *__restrict__
     const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
     v = w[((size_t)co * 32 + ci) * 27 + (dy * 3 + dx) * 3 + dz];
   }
-  const int ntm = f16 ? 1 : 3;
+  const int ntm = f16 == 1 ? 1 : 3;
   const size_t base = (((size_t)(nb * 2 + ks) * ntm) * 64 + lane) * 8 + j;
-  if (f16) {
+  if (f16 == 2) {                                  // h2: f16 hi / mid of w * 2^k in the three-term slots (the third stays zero)
+    const float vs = v * wscale;
+    const _Float16 h = (_Float16)vs;
+    const _Float16 md = (_Float16)(vs - (float)h);
+    out[base] = __builtin_bit_cast(unsigned short, h);
+    out[base + (size_t)64 * 8] = __builtin_bit_cast(unsigned short, md);
+    out[base + (size_t)2 * 64 * 8] = 0;
+  } else if (f16) {
     const _Float16 h = (_Float16)v;
     out[base] = __builtin_bit_cast(unsigned short, h);
   } else {
@@ -295,8 +316,8 @@ __global__ __launch_bounds__(256) void fin_pack_kernel(const float *__restrict__
   }
 }
 
-hipError_t launch_fin_pack(const float *w_ref, float *wfin, int Co, bool f16, hipStream_t st) {
-  hipLaunchKernelGGL(fin_pack_kernel, dim3(16), dim3(256), 0, st, w_ref, reinterpret_cast<unsigned short *>(wfin), Co, f16 ? 1 : 0);
+hipError_t launch_fin_pack(const float *w_ref, float *wfin, int Co, int mode, hipStream_t st, float wscale) {
+  hipLaunchKernelGGL(fin_pack_kernel, dim3(16), dim3(256), 0, st, w_ref, reinterpret_cast<unsigned short *>(wfin), Co, mode, wscale);
   return hipGetLastError();
 }
 

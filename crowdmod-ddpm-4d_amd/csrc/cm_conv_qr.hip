@@ -29,6 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 typedef __bf16 bf16x8q __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8q __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4q __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float silu_q(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void conv_qr_kernel(const QrArgs a) {
 // B6: fp32 products from exact three-way bf16 splits (cm_conv_ups.hip explains the arithmetic).  A step is 16 channels (the
 // wave's range padded with zeros to whole steps), its slice holds three bf16 planes per voxel (single-buffered: the waves
 // have one or two steps), a tap is 4 (plane, z tap) pairs x 6 v_mfma_f32_32x32x16_bf16.  The fused skip conv stays fp32.
-template <int MBP, bool SKIP, bool B6 = false>
+template <int MBP, bool SKIP, int B6 = 0>         // B6: 0 fp32 matrix instruction, 1 six bf16 cross terms, 2 three (relaxed plan), 3 three f16 cross terms (h2)
 __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
   constexpr int MB = 2 * MBP;
   constexpr int SS = B6 ? 28 : 12;                 // slice row stride in floats: 8 channels + 4 pad (conflict-free 16-byte reads); B6: 3 x 8 + 4
@@ -429,10 +430,12 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
         if (ioff[k] < 0 || !cq_ok) w = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (B6) {
           if (hv < HV) {
+            constexpr int NTW = B6 >= 2 ? 2 : 3;
             cm_u32x2_t t3[3];
-            cm_split3_bf16(w, t3);                  // hi / mid / lo planes, exact remainders
+            if constexpr (B6 == 3) cm_split2_f16(w, t3);   // h2: f16 hi / mid (bounded input: GroupNorm + SiLU output)
+            else cm_split3_bf16<NTW>(w, t3);        // hi / mid / lo planes, exact remainders
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<cm_u32x2_t *>(dst + (size_t)hv * SS + 8 * tm) = t3[tm];
+            for (int tm = 0; tm < NTW; ++tm) *reinterpret_cast<cm_u32x2_t *>(dst + (size_t)hv * SS + 8 * tm) = t3[tm];
           }
         } else {
           if (hv < HV) *reinterpret_cast<f32x4 *>(dst + (size_t)hv * SS) = w;
@@ -502,8 +505,12 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
         constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
         auto six = [&](f32x16 &d, const f32x4 (&av)[3], const f32x4 (&wv)[3]) {
 #pragma unroll
-          for (int u = 0; u < 6; ++u)
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8q, av[TA[u]]), __builtin_bit_cast(bf16x8q, wv[TB[u]]), d, 0, 0, 0);
+          for (int u = (B6 >= 2 ? 3 : 0); u < 6; ++u) {
+            if constexpr (B6 == 3)
+              d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8q, av[TA[u]]), __builtin_bit_cast(f16x8q, wv[TB[u]]), d, 0, 0, 0);
+            else
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8q, av[TA[u]]), __builtin_bit_cast(bf16x8q, wv[TB[u]]), d, 0, 0, 0);
+          }
         };
 #pragma unroll
         for (int j = 0; j < MBP; ++j) {
@@ -598,7 +605,8 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
       const bool s0 = c < a.s2C0;
       const float *sp = s0 ? a.s2src0 + (size_t)b * V * a.s2C0 + c : a.s2src1 + (size_t)b * V * a.s2C1 + (c - a.s2C0);
       const int Cs = s0 ? a.s2C0 : a.s2C1;
-      const f32x4 w4 = ws[(size_t)gs * 64];
+      f32x4 w4 = ws[(size_t)gs * 64];
+      if constexpr (B6 == 3) w4 = w4 * (1.0f / a.h2_oscale);   // (the main accumulators hold 2^k times the sum: same scale, exact)
       f32x4 av[MB];
 #pragma unroll
       for (int i = 0; i < MB; ++i) {
@@ -635,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
     for (int e = 0; e < 4; ++e) {
       const int v = j * 32 + 8 * q + 4 * hh + e;
       oidx[i][e] = v < PV ? pz * PV + v : -1;
-      val[i][e] = s[e] + bias_pre + tv_pre;
+      val[i][e] = (B6 == 3 ? s[e] * a.h2_oscale : s[e]) + bias_pre + tv_pre;
     }
   }
   if (a.resid) {
@@ -789,13 +797,29 @@ hipError_t launch_conv_qr(const QrArgs &a_in, hipStream_t st) {
     hipLaunchKernelGGL(KERNEL, grid, dim3(512), lds, st, a);                                        \
     return hipGetLastError();                                                                       \
   }
+  if (b6 && a.three == 2) {                           // default plan: h2 fragments, three f16 cross terms
+    if (MBP == 1) {
+      if (a.s2w) CM_QR_GO((conv_qr2_kernel<1, true, 3>))
+      CM_QR_GO((conv_qr2_kernel<1, false, 3>))
+    }
+    if (a.s2w) CM_QR_GO((conv_qr2_kernel<2, true, 3>))
+    CM_QR_GO((conv_qr2_kernel<2, false, 3>))
+  }
+  if (b6 && a.three) {                                // relaxed plan: three cross terms on the same fragments
+    if (MBP == 1) {
+      if (a.s2w) CM_QR_GO((conv_qr2_kernel<1, true, 2>))
+      CM_QR_GO((conv_qr2_kernel<1, false, 2>))
+    }
+    if (a.s2w) CM_QR_GO((conv_qr2_kernel<2, true, 2>))
+    CM_QR_GO((conv_qr2_kernel<2, false, 2>))
+  }
   if (b6) {
     if (MBP == 1) {
-      if (a.s2w) CM_QR_GO((conv_qr2_kernel<1, true, true>))
-      CM_QR_GO((conv_qr2_kernel<1, false, true>))
+      if (a.s2w) CM_QR_GO((conv_qr2_kernel<1, true, 1>))
+      CM_QR_GO((conv_qr2_kernel<1, false, 1>))
     }
-    if (a.s2w) CM_QR_GO((conv_qr2_kernel<2, true, true>))
-    CM_QR_GO((conv_qr2_kernel<2, false, true>))
+    if (a.s2w) CM_QR_GO((conv_qr2_kernel<2, true, 1>))
+    CM_QR_GO((conv_qr2_kernel<2, false, 1>))
   }
   if (v2) {
     if (MBP == 1) {

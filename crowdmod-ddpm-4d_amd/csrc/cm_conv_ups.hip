@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
   // 4.1e-7 of the k-ordered fp32 chain, three terms 4.4e-6; measured: whole-forward error against the reference 2.1e-6, exact-fp32 path 2.3e-6),
   // and 16 channels take 6 x 32 cycles instead of 8 x 64.  The staged box is split once per voxel at the LDS write (three
   // bf16 planes per row), the weights arrive pre-split (pack_ups_b6).
-  constexpr bool F16 = PREC == 1, B6 = PREC == 2;
+  constexpr bool F16 = PREC == 1, B6 = PREC == 2 || PREC == 3;   // 3: relaxed plan -- three cross terms on the six-term fragments
+  constexpr int U0 = PREC == 3 ? 3 : 0, NTW = PREC == 3 ? 2 : 3;
   constexpr int NTM = B6 ? 3 : 1;                // operand terms
   constexpr int S = B6 ? 52 : (F16 ? 20 : 36);   // LDS row stride in dwords: 32 channels (x 3 bf16 planes) + pad
   constexpr int NST = PREC ? 16 : 32;            // steps per 32-channel chunk
@@ -163,10 +164,10 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
           const f32x4 w = ((hok >> k) & 1u) ? ld[kk] : f32x4{0.f, 0.f, 0.f, 0.f};
           if constexpr (B6) {
             cm_u32x2_t t3[3];
-            cm_split3_bf16(w, t3);                  // hi / mid / lo planes, exact remainders
+            cm_split3_bf16<NTW>(w, t3);             // hi / mid / lo planes, exact remainders
             if (h < HV) {
 #pragma unroll
-              for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<cm_u32x2_t *>(A + (size_t)h * S + 16 * tm + 2 * q) = t3[tm];
+              for (int tm = 0; tm < NTW; ++tm) *reinterpret_cast<cm_u32x2_t *>(A + (size_t)h * S + 16 * tm + 2 * q) = t3[tm];
             }
           } else if constexpr (F16) {
             const f16x4 hv = {(_Float16)w[0], (_Float16)w[1], (_Float16)w[2], (_Float16)w[3]};
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int u = 0; u < 6; ++u)
+            for (int u = U0; u < 6; ++u)
               acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[s & 1][TA[u]][j]),
                                                                    __builtin_bit_cast(bf16x8, bw[s % RD][TB[u]][nb]), acc[j][nb], 0, 0, 0);
         } else if constexpr (F16) {
@@ -460,8 +461,8 @@ hipError_t launch_conv_ups(const ConvArgs &a_in, int mbw, int planes, int nbp, h
   hipError_t et = ups_tabs_get(a, mbw, planes, &tb);
   if (et != hipSuccess) return et;
   const int nb = ups_nb(a, mbw, nbp), occ = ups_occ(mbw);   // (a workgroup's NB column blocks sit in one packed n tile)
-  const int prec = a.f16;                          // 0: fp32 matrix instruction, 1: f16 operands, 2: bf16 x 6 split products
-  const size_t lds = (size_t)tb.HV * (prec == 2 ? 52 : (prec == 1 ? 20 : 36)) * sizeof(float);
+  const int prec = a.f16;                          // 0: fp32 matrix instruction, 1: f16 operands, 2: bf16 x 6 split products, 3: three of the six
+  const size_t lds = (size_t)tb.HV * (prec >= 2 ? 52 : (prec == 1 ? 20 : 36)) * sizeof(float);
   const dim3 grid((unsigned)(a.B * tb.ntp), (unsigned)(a.Co / (32 * nb)), 2);
   const int HX = a.bx + 2, HYX = (a.by + 2) * HX;
 #define CM_UPS_GO(M, N, O, H)                                                                       \
@@ -477,7 +478,7 @@ hipError_t launch_conv_ups(const ConvArgs &a_in, int mbw, int planes, int nbp, h
     hipLaunchKernelGGL((conv_ups_kernel<M, N, O, H>), grid, dim3(256), lds, st, a, tb.tH, tb.tM, tb.HV, tb.ntp, HX, HYX, planes, nbp); \
     return hipGetLastError();                                                                       \
   }
-#define CM_UPS_OCCS(M, N) CM_UPS_GO(M, N, 2, 0) CM_UPS_GO(M, N, 2, 1) CM_UPS_GO(M, N, 2, 2)
+#define CM_UPS_OCCS(M, N) CM_UPS_GO(M, N, 2, 0) CM_UPS_GO(M, N, 2, 1) CM_UPS_GO(M, N, 2, 2) CM_UPS_GO(M, N, 2, 3)
   CM_UPS_OCCS(1, 1) CM_UPS_OCCS(2, 1) CM_UPS_OCCS(3, 1) CM_UPS_OCCS(4, 1) CM_UPS_OCCS(5, 1) CM_UPS_OCCS(2, 2)
 #undef CM_UPS_OCCS
 #undef CM_UPS_GO

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256 * NBW, OCC) void conv_wino_kernel(const ConvArg
 #ifndef CM_WINO_ABL
 #define CM_WINO_ABL 0        // compile-time ablations of the six-term chunk loop (experiments only; results are wrong)
 #endif
-template <int BZ, int PY, int PX, bool F16, int NBW, bool SKIP, bool B6 = false>
+template <int BZ, int PY, int PX, bool F16, int NBW, bool SKIP, int B6 = 0>   // B6: 0 off, 1 six bf16 cross terms, 2 three (relaxed plan), 3 three f16 cross terms (h2)
 __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArgs a, const int *__restrict__ tabA,
                                                                   const int *__restrict__ tabO, int G) {
   constexpr int NT = 256 * NBW;
@@ -764,10 +764,12 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
           for (int j = 0; j < 4; ++j) d[i * 4 + j] = *reinterpret_cast<const f32x4 *>(R + rbase + (i * RXH + j) * RS_);
         auto put = [&](int k, const f32x4 v) {     // component k = xi_y * 4 + xi_x of this item
           if constexpr (B6) {
+            constexpr int NTW = B6 >= 2 ? 2 : 3;    // (relaxed plan / h2: the lo plane is neither formed nor written nor read)
             cm_u32x2_t t3[3];
-            cm_split3_bf16(v, t3);                  // hi / mid / lo planes, exact remainders
+            if constexpr (B6 == 3) cm_split2_f16(v, t3);   // h2: f16 hi / mid of the transformed GroupNorm + SiLU output (bounded)
+            else cm_split3_bf16<NTW>(v, t3);        // hi / mid / lo planes, exact remainders
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<cm_u32x2_t *>(uw + (size_t)k * URC * S + TST * tm) = t3[tm];
+            for (int tm = 0; tm < NTW; ++tm) *reinterpret_cast<cm_u32x2_t *>(uw + (size_t)k * URC * S + TST * tm) = t3[tm];
           } else if constexpr (F16) {
             const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             *reinterpret_cast<f16x4 *>(uw + (size_t)k * URC * S) = hv;
@@ -837,9 +839,14 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
           // (A term, B term), small products first: hi = 0, mid = 1, lo = 2
           constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-          for (int u = 0; u < ((CM_WINO_ABL & 8) ? 1 : 6); ++u)
-            acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af6[sx & 1][TA[u]]),
-                                                             __builtin_bit_cast(bf16x8, b6[sx % RD6][TB[u]]), acc[x], 0, 0, 0);
+          for (int u = (B6 >= 2 ? 3 : 0); u < ((CM_WINO_ABL & 8) ? (B6 >= 2 ? 4 : 1) : 6); ++u) {
+            if constexpr (B6 == 3)
+              acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af6[sx & 1][TA[u]]),
+                                                              __builtin_bit_cast(f16x8, b6[sx % RD6][TB[u]]), acc[x], 0, 0, 0);
+            else
+              acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af6[sx & 1][TA[u]]),
+                                                               __builtin_bit_cast(bf16x8, b6[sx % RD6][TB[u]]), acc[x], 0, 0, 0);
+          }
           // refill the slot just read with step sx + RD6 (of this chunk, the next one, or the next sample's first)
           {
             constexpr int CHS = 4 * NG * 4 * 3 * 64;
@@ -921,6 +928,7 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
         v[4 * q] = w4[0]; v[4 * q + 1] = w4[1]; v[4 * q + 2] = w4[2]; v[4 * q + 3] = w4[3];
       }
     }
+    if constexpr (B6 == 3) v = v * a.h2_oscale;   // (h2 fragments hold w * 2^k; the skip conv below adds to the unscaled sums)
     if constexpr (SKIP) {
       // operands requested only now, one 32-channel chunk at a time (requesting them under the output transform, or double
       // buffering them, was the register peak of the kernel and spilled into the chunk loop)
@@ -1177,7 +1185,8 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
   a.dbg = conv_dbg_flags();
   if (!conv_wino_ok(a)) return hipErrorInvalidValue;
   const int nbw = conv_wino_nbw(a.bz, a.Co);
-  const bool b6 = a.f16 == 2;
+  const bool b6 = a.f16 == 2 || a.f16 == 3 || a.f16 == 4;   // 3: the relaxed plan's three-term form on the same fragments;
+  const bool t3 = a.f16 == 3, h2 = a.f16 == 4;               // 4: h2 fragments (f16 hi / mid of w * 2^k), three f16 cross terms
   if (b6 && (f16 || !conv_wino_b6_ok(a.bz, a.by, a.bx, a.Co, a.Zo))) return hipErrorInvalidValue;
   static const bool no_p = cm::diag_env("CM_NO_WINO_P") != nullptr;
 #define CM_WINO_ATTR(KERNEL)                                                                        \
@@ -1220,16 +1229,21 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
     if (a.s2w) CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, F, NB, true>), THREADS)                \
     CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, F, NB, false>), THREADS)                          \
   }
-#define CM_WINO_PGO61(Z, PY_, PX_, THREADS)                                                         \
+#define CM_WINO_PGO6N(Z, PY_, PX_, NB, THREADS)                                                     \
   {                                                                                                 \
-    if (a.s2w) CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, 1, true, true>), THREADS)       \
-    CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, 1, false, true>), THREADS)                 \
+    if (h2) {                                                                                       \
+      if (a.s2w) CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, NB, true, 3>), THREADS)       \
+      CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, NB, false, 3>), THREADS)                 \
+    }                                                                                               \
+    if (t3) {                                                                                       \
+      if (a.s2w) CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, NB, true, 2>), THREADS)       \
+      CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, NB, false, 2>), THREADS)                 \
+    }                                                                                               \
+    if (a.s2w) CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, NB, true, 1>), THREADS)         \
+    CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, NB, false, 1>), THREADS)                   \
   }
-#define CM_WINO_PGO6(Z, PY_, PX_, THREADS)                                                          \
-  {                                                                                                 \
-    if (a.s2w) CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, 2, true, true>), THREADS)       \
-    CM_WINO_PGO1((conv_wino_p_kernel<Z, PY_, PX_, false, 2, false, true>), THREADS)                 \
-  }
+#define CM_WINO_PGO61(Z, PY_, PX_, THREADS) CM_WINO_PGO6N(Z, PY_, PX_, 1, THREADS)
+#define CM_WINO_PGO6(Z, PY_, PX_, THREADS) CM_WINO_PGO6N(Z, PY_, PX_, 2, THREADS)
 #define X(z, py, px)                                                                                \
     if (a.bz == z && a.by == 2 * py && a.bx == 2 * px && ldsp <= 160 * 1024) {                      \
       if constexpr (z != 8) {                                                                       \

@@ -39,16 +39,33 @@ __device__ __forceinline__ unsigned cm_cvt_pk_bf16(float a, float b) {
   const cm_f32x2_t v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, cm_bf16x2_t));
 }
+// NT = 2: only hi and mid (the relaxed plan's two-way split: three cross terms hi x mid, mid x hi, hi x hi, ~16 mantissa bits per
+// product); t[2] is left untouched.
+template <int NT = 3>
 __device__ __forceinline__ void cm_split3_bf16(cm_f32x4_t x, cm_u32x2_t (&t)[3]) {
 #pragma unroll
-  for (int tm = 0; tm < 3; ++tm) {
+  for (int tm = 0; tm < NT; ++tm) {
     const unsigned p01 = cm_cvt_pk_bf16(x[0], x[1]), p23 = cm_cvt_pk_bf16(x[2], x[3]);
     t[tm] = cm_u32x2_t{p01, p23};
-    if (tm < 2) {
+    if (tm < NT - 1) {
       x[0] -= __uint_as_float(p01 << 16); x[1] -= __uint_as_float(p01 & 0xffff0000u);
       x[2] -= __uint_as_float(p23 << 16); x[3] -= __uint_as_float(p23 & 0xffff0000u);
     }
   }
+}
+// Two-way f16 split of four fp32 values (the default plan's "h2" arithmetic on layers whose input is GroupNorm + SiLU output, i.e.
+// bounded): hi = RNE_f16(x), mid = RNE_f16(x - hi) (the remainder x - hi is exact in fp32).  hi + mid carries 22 of the 24 mantissa
+// bits; three cross terms hi x mid, mid x hi, hi x hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation give the accuracy of the
+// six-term bf16 form (tools/sim_six_term.py: 9.8e-7 rms against fp64 for both, 5.2e-7 for a plain fp32 chain) at half the matrix
+// instructions and a 12- instead of 22-instruction split.  f16 has 5 exponent bits: callers bound their operands.
+typedef _Float16 cm_f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cm_split2_f16(cm_f32x4_t x, cm_u32x2_t (&t)[3]) {
+  const cm_f32x2_t a = {x[0], x[1]}, b = {x[2], x[3]};
+  const cm_f16x2_t ha = __builtin_convertvector(a, cm_f16x2_t), hb = __builtin_convertvector(b, cm_f16x2_t);
+  t[0] = cm_u32x2_t{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+  const cm_f32x2_t ra = a - __builtin_convertvector(ha, cm_f32x2_t), rb = b - __builtin_convertvector(hb, cm_f32x2_t);
+  const cm_f16x2_t ma = __builtin_convertvector(ra, cm_f16x2_t), mb = __builtin_convertvector(rb, cm_f16x2_t);
+  t[1] = cm_u32x2_t{__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};
 }
 #endif
 
@@ -113,6 +130,9 @@ struct ConvArgs {
   // implement it ever receive a non-zero mask (cm_model.cpp: plan_h16): conv_f16d, conv_first (out), conv_ups (f16 form),
   // conv_smalln (src).  Accumulation, GroupNorm statistics (taken from the fp32 accumulators), SiLU and the sampler stay fp32.
   int h16;
+  // Default plan, "h2" layers (a.f16 == 4): the weight fragments hold f16 hi / mid terms of w * 2^k (cm_split2_f16; k chosen per
+  // layer at pack time so that the mid terms are normal numbers); the kernel multiplies its accumulators by h2_oscale = 2^-k.
+  float h2_oscale;
   // Round 4 -- GroupNorm statistics WITHOUT the gn_finalize launch (inference plan).  Producer side: instead of slot partials,
   // every 32-row block ADDS its per-channel sums to astat[b][astat_C][3] (64-bit fixed point: sum x * 2^16 as two's complement,
   // floor(sum x^2 / 2^32), (sum x^2 mod 2^32) * 2^20): integer adds are exact and order-independent, so the totals are
@@ -318,6 +338,9 @@ struct QrArgs {
   int silu;
   float *gn_out;                 // optional [B][2][C0 + C1] copy of the folded scale / shift rows
   const float *wq6;              // optional: the same weights as exact bf16 x 3 splits (pack_qr_b6) -> six-term products in conv_qr2
+  int three;                     // with wq6: 1 = only the three leading cross terms (relaxed plan, cm_model_set_precision);
+                                 // 2 = wq6 holds h2 fragments (f16 hi / mid of w * 2^k, cm_split2_f16): three f16 cross terms
+  float h2_oscale;               //     ... and the accumulators are multiplied by 2^-k
   const float *wq;               // [Co / 32][g = k8 * 9 + dy * 3 + dx][dz][64 lanes][4]: W[co = 32 nt + lane % 32][ci = 8 k8 + 4 (lane / 32) + jj][(dz, dy, dx)]
   const float *bias;
   const float *temb;
@@ -371,8 +394,8 @@ hipError_t launch_b6d_repack(const float *w, float *w6, int Co, int Ci, int taps
 // a.by / a.bx = in-plane tile of conv_fin_pick; wfin = launch_fin_pack fragments (three bf16 terms, or one f16 term with f16 = true)
 bool conv_fin_pick(int Y, int X, int *by, int *bx);
 bool conv_fin_ok(const ConvArgs &a);
-hipError_t launch_conv_fin(const ConvArgs &a, const float *wfin, bool f16, hipStream_t st);
-hipError_t launch_fin_pack(const float *w_ref /*[Co][32][3][3][3] reference layout, device*/, float *wfin, int Co, bool f16, hipStream_t st);
+hipError_t launch_conv_fin(const ConvArgs &a, const float *wfin, int mode /*0 six bf16 terms, 1 f16, 2 three bf16 terms, 3 three f16 terms (h2)*/, hipStream_t st);
+hipError_t launch_fin_pack(const float *w_ref /*[Co][32][3][3][3] reference layout, device*/, float *wfin, int Co, int mode /*0 three bf16 terms, 1 one f16 term, 2 f16 hi / mid of w * wscale*/, hipStream_t st, float wscale = 1.f);
 constexpr size_t CM_FIN_W_FLOATS = 4 * 2 * 3 * 64 * 4;   // fragment floats (six-term form; the f16 form uses a third)
 
 // ---- small kernels --------------------------------------------------------

@@ -124,9 +124,16 @@ struct Op {
   float *d_wups_b6 = nullptr;   // fp32 plan, inference forward: bf16 x 3 split fragments (pack_ups_b6) for the six-term products
   long long wups_b6_stride = 0;
   float *d_w16d = nullptr, *d_w16d_skip = nullptr;
+  bool dbg_h2 = false;      // cm_debug_conv_io mode 2: raw sources, but the h2 form where the plan has one (the caller bounds its operands)
   bool dbg_raw = false;     // cm_debug_conv_io: the whole-sample quarter-resolution kernel without its GroupNorm (raw sources)
   bool b6d = false;         // fp32 plan: direct six-term kernel (cm_conv_b6d.hip) instead of the six-term Winograd one (inference forward)
   int b6d_bz = 0, b6d_by = 0, b6d_bx = 0, b6d_nw = 0, b6d_mbw = 0;
+  // default plan, layers whose input is GroupNorm + SiLU output (bounded): f16 two-way splits, three cross terms ("h2", cm_kernels.h:
+  // cm_split2_f16) instead of bf16 three-way splits, six cross terms -- same accuracy, half the matrix instructions.  Fragments of
+  // w * 2^k; h2_oscale = 2^-k.  Inference-only handles (a handle that trains keeps the six-term form: its repack kernels do not
+  // maintain these fragments).
+  float *d_wfin_h2 = nullptr, *d_wwino_h2 = nullptr, *d_wqr_h2 = nullptr;
+  float h2_oscale = 1.f;
   bool b6s2 = false;        // fp32 plan: the stride-2 DownSample conv on the same kernel (tile fields above)
   float *d_wb6d = nullptr, *d_wb6d_skip = nullptr;
   bool qr = false;          // whole-sample kernel of the lowest resolution (cm_conv_qr.hip), inference plan
@@ -507,6 +514,13 @@ static inline float bf16_bits_to_f32(uint16_t h) {
 }
 // exact three-way bf16 split of an fp32 value: w = hi + mid + lo (each rounded to nearest from the running remainder;
 // 8 + 8 + 8 mantissa bits, the remainders are exact in fp32)
+// h2 terms of one weight (cm_kernels.h: cm_split2_f16): f16 hi / mid of w * scale, third slot zero
+static inline void f16_split2(float w, float scale, uint16_t out[3]) {
+  const float v = w * scale;
+  out[0] = f32_to_f16_bits(v);
+  out[1] = f32_to_f16_bits(v - f16_bits_to_f32(out[0]));
+  out[2] = 0;
+}
 static inline void bf16_split3(float w, uint16_t out[3]) {
   float rem = w;
   for (int t = 0; t < 3; ++t) {
@@ -641,7 +655,8 @@ std::vector<float> pack_wino_f16(const std::vector<float> &wi, int Co, int Ci, i
 // bf16 terms and regrouped as [n tile][chunk][xi_y][dz][xi_x][term][lane][8 bf16], ci = chunk * 16 + 8 hh + j.  The device
 // re-derives the same thing after an optimizer step (wino_b6_repack_kernel): one definition, two places -- the self-test
 // compares them element by element.
-std::vector<float> pack_wino_b6(const std::vector<float> &ww) {
+// h2_scale > 0: the h2 form instead -- f16 hi / mid of w * h2_scale in the first two term slots (same layout, third slot zero)
+std::vector<float> pack_wino_b6(const std::vector<float> &ww, float h2_scale = 0.f) {
   std::vector<uint16_t> out(ww.size() * 3, 0);
   for (size_t i = 0; i < ww.size(); ++i) {
     const int jj = (int)(i & 3), lane = (int)((i >> 2) & 63);
@@ -652,7 +667,8 @@ std::vector<float> pack_wino_b6(const std::vector<float> &ww) {
     const int xx = step & 3, k8 = (step >> 2) & 1, dz = step >> 3;
     const int r = lane & 31, hs = lane >> 5, cl = 8 * k8 + 4 * hs + jj, hd = cl >> 3, j = cl & 7;
     uint16_t t3[3];
-    bf16_split3(ww[i], t3);
+    if (h2_scale > 0.f) f16_split2(ww[i], h2_scale, t3);
+    else bf16_split3(ww[i], t3);
     for (int tm = 0; tm < 3; ++tm)
       out[(((((((tc * 4 + xy) * 3 + dz) * 4 + xx) * 3 + tm) * 64) + 32 * hd + r) * 8) + j] = t3[tm];
   }
@@ -881,7 +897,7 @@ std::vector<float> pack_qr(const std::vector<float> &wi, int Co, int Ci) {
 // (wave w owns the channels [w Ci/8, (w+1) Ci/8), padded with zeros to whole 16-channel steps):
 // [Co/32][wave 8][step][tap 9][dz][term][lane][8 bf16], ci = wave * Ci/8 + 16 step + 8 hh + j.  `wq` is pack_qr's output.
 // The device re-derives it after an optimizer step with the same index arithmetic (qr_b6_repack_kernel).
-std::vector<float> pack_qr_b6(const std::vector<float> &wq, int Co, int Ci) {
+std::vector<float> pack_qr_b6(const std::vector<float> &wq, int Co, int Ci, float h2_scale = 0.f) {
   const int ntn = Co / 32, K8 = Ci / 8, ng = 9 * K8, cw = Ci / 8, nsw = (cw + 15) / 16;
   std::vector<uint16_t> out((size_t)ntn * 8 * nsw * 9 * 3 * 3 * 64 * 8, 0);
   for (size_t i = 0; i < wq.size(); ++i) {
@@ -893,7 +909,8 @@ std::vector<float> pack_qr_b6(const std::vector<float> &wq, int Co, int Ci) {
     const int k8 = g / 9, t9 = g % 9, ci = 8 * k8 + 4 * (lane >> 5) + jj, r = lane & 31;
     const int wv = ci / cw, cl = ci % cw, st = cl / 16, hd = (cl % 16) / 8, j = cl % 8;
     uint16_t t3[3];
-    bf16_split3(wq[i], t3);
+    if (h2_scale > 0.f) f16_split2(wq[i], h2_scale, t3);
+    else bf16_split3(wq[i], t3);
     for (int tm = 0; tm < 3; ++tm)
       out[(((((((size_t)(nt * 8 + wv) * nsw + st) * 9 + t9) * 3 + dz) * 3 + tm) * 64) + 32 * hd + r) * 8 + j] = t3[tm];
   }
@@ -912,6 +929,31 @@ std::vector<float> pack_qr_skip(const float *w2, int Co, int Cs) {
         for (int jj = 0; jj < 4; ++jj, ++o)
           out[o] = w2[(size_t)(nt * 32 + (lane & 31)) * Cs + 8 * gs + 4 * (lane >> 5) + jj];
   return out;
+}
+
+// ---- "h2" arithmetic (cm_kernels.h: cm_split2_f16): operand range management ---------------------------------------------------
+// f16 has 5 exponent bits.  Weights: packed as w * 2^k with max |w| 2^k in [4096, 8192) (their mid terms ~ 2^-11 of that stay normal
+// numbers; 8x headroom below 65504); the kernel multiplies its fp32 accumulators by 2^-k (exact).  Activations: a GroupNorm output
+// satisfies |z| < sqrt(n) for a group of n elements, so |SiLU(gamma z + beta)| <= sqrt(n) max|gamma| + max|beta|, times `gain` for a
+// linear input transform (4 for the Winograd B^T d B: sums of four values).  A layer whose bound exceeds 32000 keeps the six-term
+// bf16 form (bf16 has the exponent range of fp32).
+static float h2_wscale(const float *w, size_t n) {
+  float mx = 0.f;
+  for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w[i]));
+  if (!(mx > 0.f) || !std::isfinite(mx)) return 0.f;
+  int e = 0;
+  (void)std::frexp(mx, &e);                        // mx = f * 2^e, f in [0.5, 1)
+  return std::ldexp(1.0f, 13 - e);                 // mx * 2^(13 - e) in [4096, 8192)
+}
+static bool h2_act_bounded(const cm_model *m, const Op &gop, double gain) {
+  const std::vector<float> &g = P(m, gop.gname).host, &b = P(m, gop.bename).host;
+  double gm = 0, bm = 0;
+  for (float v : g) gm = std::max(gm, (double)std::fabs(v));
+  for (float v : b) bm = std::max(bm, (double)std::fabs(v));
+  const int Ct = gop.g0->C + (gop.g1 ? gop.g1->C : 0);
+  const double n = (double)(Ct / GN_GROUPS) * gop.g0->V();
+  const double bound = (std::sqrt(n) * gm + bm) * gain;
+  return std::isfinite(bound) && bound <= 32000.0;
 }
 
 // Which Winograd-eligible layers take the direct six-term kernel instead.  Round 4, same-box A/B on the full-resolution layers
@@ -1055,10 +1097,10 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     if (s.Co <= 4 && Ci_ref == 32 && Ci_pad == 32 && !s.s1 && !cm::diag_env("CM_NO_FIN") && cm::conv_fin_pick(s.out->Y, s.out->X, &op.fin_by, &op.fin_bx)) {
       if (upload(m, w.host, &op.d_wfin_src)) return 1;
       if (dev_alloc(m, (void **)&op.d_wfin, cm::CM_FIN_W_FLOATS * sizeof(float))) return 1;
-      CM_HIP(cm::launch_fin_pack(op.d_wfin_src, op.d_wfin, s.Co, false, m->stream));
+      CM_HIP(cm::launch_fin_pack(op.d_wfin_src, op.d_wfin, s.Co, 0, m->stream));
       if (m->precision == CM_PRECISION_F16) {
         if (dev_alloc(m, (void **)&op.d_wfin16, cm::CM_FIN_W_FLOATS * sizeof(float))) return 1;
-        CM_HIP(cm::launch_fin_pack(op.d_wfin_src, op.d_wfin16, s.Co, true, m->stream));
+        CM_HIP(cm::launch_fin_pack(op.d_wfin_src, op.d_wfin16, s.Co, 1, m->stream));
       }
       CM_HIP(hipStreamSynchronize(m->stream));
       op.fin = true;
@@ -1145,6 +1187,25 @@ int add_conv(cm_model *m, const ConvSpec &s) {
   if (s.gn)
     for (int i = (int)m->ops.size() - 1; i >= 0; --i)
       if (m->ops[i].kind == OP_GNFIN && m->ops[i].gn_out == s.gn) { op.gn_op = i; break; }
+  const bool h2_plan = m->precision == CM_PRECISION_F32 && !cm::diag_env("CM_NO_H2") && s.gn && op.gn_op >= 0 && s.silu;
+  if (op.fin && h2_plan && h2_act_bounded(m, m->ops[op.gn_op], 1.0)) {
+    const float ws = h2_wscale(w.host.data(), w.host.size());
+    if (ws > 0.f) {
+      if (dev_alloc(m, (void **)&op.d_wfin_h2, cm::CM_FIN_W_FLOATS * sizeof(float))) return 1;
+      CM_HIP(cm::launch_fin_pack(op.d_wfin_src, op.d_wfin_h2, s.Co, 2, m->stream, ws));
+      CM_HIP(hipStreamSynchronize(m->stream));
+      op.h2_oscale = 1.f / ws;
+    }
+  }
+  if (op.wino && op.d_wwino_b6 && h2_plan && h2_act_bounded(m, m->ops[op.gn_op], 4.0)) {
+    std::vector<float> ww;
+    pack_wino(&wi, nullptr, s.Co, Ci_ref, Ci_pad, &ww, nullptr, nullptr);
+    const float ws = h2_wscale(ww.data(), ww.size());
+    if (ws > 0.f) {
+      if (upload(m, pack_wino_b6(ww, ws), &op.d_wwino_h2)) return 1;
+      op.h2_oscale = 1.f / ws;
+    }
+  }
   // Tiny-spatial layers (one 54-voxel tile per sample at quarter resolution): the only way to
   // more parallelism AND less weight traffic per workgroup is to split K over workgroups;
   // a second pass sums the partials in a fixed order and applies the epilogue.
@@ -1207,6 +1268,13 @@ int add_conv(cm_model *m, const ConvSpec &s) {
         op.wqr_floats = (long long)wq.size();
         if (m->precision != CM_PRECISION_F16 && Ci_ref % 64 == 0 && !cm::diag_env("CM_NO_QR_B6") && upload(m, pack_qr_b6(wq, s.Co, Ci_ref), &op.d_wqr_b6))
           return 1;
+        if (op.d_wqr_b6 && h2_plan && h2_act_bounded(m, m->ops[op.gn_op], 1.0)) {
+          const float ws = h2_wscale(wq.data(), wq.size());
+          if (ws > 0.f) {
+            if (upload(m, pack_qr_b6(wq, s.Co, Ci_ref, ws), &op.d_wqr_h2)) return 1;
+            op.h2_oscale = 1.f / ws;
+          }
+        }
       }
       if (op.d_s2w) {
         const Param &w2 = P(m, s.skip_w);
@@ -1593,6 +1661,11 @@ int run_conv_qr(cm_model *m, Op &op, int B, hipStream_t st, int b0) {
   if (op.dbg_raw) { q.gamma = q.beta = nullptr; q.raw = 1; q.silu = 0; }
   q.wq = op.d_wqr; q.bias = ca.bias;
   q.wq6 = op.d_wqr_b6;
+  q.three = (m->precision == CM_PRECISION_F32R && !m->train_fwd) ? 1 : 0;
+  // default plan, inference-only handle: the f16 two-way-split form (bounded input: GroupNorm + SiLU inside the kernel)
+  if (m->precision == CM_PRECISION_F32 && !m->train_fwd && !m->train && op.d_wqr_h2 && (!op.dbg_raw || op.dbg_h2)) {
+    q.wq6 = op.d_wqr_h2; q.three = 2; q.h2_oscale = op.h2_oscale;
+  }
   q.temb = ca.temb; q.temb_stride = ca.temb_stride; q.tidx = ca.tidx + b0;
   q.resid = ca.resid ? ca.resid + (size_t)b0 * V * ca.res_cs : nullptr; q.res_cs = ca.res_cs;
   if (m->train_fwd) {
@@ -1713,6 +1786,10 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   }
   // ---- which kernel will run (needed up front: only some kernels speak the accumulator statistics of round 4) -------------------
   static const bool no_train_b6 = cm::diag_env("CM_NO_TRAIN_B6") != nullptr;
+  // relaxed fp32 plan (cm_model_set_precision): the six-term kernels issue only their three leading cross terms (inference forward)
+  const bool relaxed = m->precision == CM_PRECISION_F32R && !m->train_fwd;
+  // default plan: the f16 two-way-split form on layers with bounded input (inference-only handles, see Op::d_wfin_h2)
+  const bool h2_live = m->precision == CM_PRECISION_F32 && !m->train_fwd && !m->train;
   cm::ConvArgs s2a = ca;
   s2a.bz = op.b6d_bz; s2a.by = op.b6d_by; s2a.bx = op.b6d_bx;
   // (the training forward as well: exact splits, fp32 accumulate; its fragments follow every optimizer step)
@@ -1805,7 +1882,7 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     // upsample conv: stage-once parity kernel with its own source tile / statistics slots (f16 operands under the
     // reduced-precision plan's inference forward)
     if (op.d_wups16 && !m->train_fwd) { ca.wfrag = op.d_wups16; ca.wpar_stride = op.wups16_stride; ca.f16 = 1; }
-    else if (op.d_wups_b6 && !(m->train_fwd && cm::diag_env("CM_NO_TRAIN_B6"))) { ca.wfrag = op.d_wups_b6; ca.wpar_stride = op.wups_b6_stride; ca.f16 = 2; }   // six-term bf16 products (training forward too)
+    else if (op.d_wups_b6 && !(m->train_fwd && cm::diag_env("CM_NO_TRAIN_B6"))) { ca.wfrag = op.d_wups_b6; ca.wpar_stride = op.wups_b6_stride; ca.f16 = relaxed ? 3 : 2; }   // six-term bf16 products (training forward too); relaxed plan: three
     ca.bz = op.ups_tz; ca.by = op.ups_ty; ca.bx = op.ups_tx;
     ca.ntz = ca.Zs / ca.bz; ca.nty = ca.Ys / ca.by; ca.ntx = ca.Xs / ca.bx;
     if (op.stat_act) {
@@ -1854,7 +1931,8 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     CM_HIP(cm::launch_conv_b6d(ca, op.b6d_nw, op.b6d_mbw, st));
   } else if (take_wino) {
     ca.wfrag = wino_f16 ? op.d_wwino16 : op.d_wwino;
-    if (wino_b6) { ca.wfrag = op.d_wwino_b6; ca.f16 = 2; }
+    if (wino_b6) { ca.wfrag = op.d_wwino_b6; ca.f16 = relaxed ? 3 : 2; }
+    if (wino_b6 && h2_live && op.d_wwino_h2 && (!op.dbg_raw || op.dbg_h2)) { ca.wfrag = op.d_wwino_h2; ca.f16 = 4; ca.h2_oscale = op.h2_oscale; }
     to_astat();
     CM_HIP(cm::launch_conv_wino(ca, wino_f16, st));
   } else if (op.first_k) {
@@ -1866,8 +1944,10 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
       cm::ConvArgs fa = ca;
       fa.by = op.fin_by; fa.bx = op.fin_bx;
       const bool f16 = op.d_wfin16 && !m->train_fwd;
+      const bool h2 = !f16 && h2_live && op.d_wfin_h2 && (!op.dbg_raw || op.dbg_h2);
+      fa.h2_oscale = op.h2_oscale;
       if (cm::conv_fin_ok(fa)) {
-        CM_HIP(cm::launch_conv_fin(fa, f16 ? op.d_wfin16 : op.d_wfin, f16, st));
+        CM_HIP(cm::launch_conv_fin(fa, f16 ? op.d_wfin16 : (h2 ? op.d_wfin_h2 : op.d_wfin), f16 ? 1 : (h2 ? 3 : (relaxed ? 2 : 0)), st));
         done = true;
       }
     }
@@ -2299,7 +2379,7 @@ int cm_model_get_param(const cm_model *m, const char *name, float *h_data, int64
 int cm_model_set_precision(cm_model *m, int32_t precision) {
   if (!m) return fail("null model handle");
   if (m->finalized) return fail("precision must be chosen before cm_model_finalize");
-  if (precision != CM_PRECISION_F32 && precision != CM_PRECISION_F16) return fail("unknown precision %d", precision);
+  if (precision != CM_PRECISION_F32 && precision != CM_PRECISION_F16 && precision != CM_PRECISION_F32R) return fail("unknown precision %d", precision);
   m->precision = precision;
   return 0;
 }
@@ -2919,6 +2999,7 @@ int cm_debug_conv_io(cm_model *m, int32_t index, int32_t mode, const float *h_in
   tmp.d_s2w = nullptr; tmp.d_wqr_skip = nullptr; tmp.skip_if_fused = false; tmp.dbg_raw = true; tmp.pm_off = -1;
   if (!tmp.qr) tmp.gn_op = -1;
   if (tmp.stat_act && tmp.stat_act->aoff >= 0) tmp.stat_act = nullptr;      // (no additions to the accumulator rows of the plan)
+  tmp.dbg_h2 = mode == 2;
   if (mode == 1) { tmp.d_wwino_b6 = nullptr; tmp.d_wqr_b6 = nullptr; tmp.d_wups_b6 = nullptr; tmp.b6d = false; tmp.b6s2 = false; }
   const int ns_keep = op.stat_act ? op.stat_act->nslots : 0;
   const int rc = run_conv(m, tmp, B, st, 0, 0);

@@ -51,8 +51,11 @@ class UNet:
         """'f32' (default: fp32 arithmetic) or 'f16': f16 matrix-core operands with fp32 accumulation in the stride-1
         3x3x3 layers, the upsample convs and -- on grids whose attention runs the generic chain -- the attention core and
         in-projection of the inference plan: the counterpart of the reference's torch.amp.autocast (ddpm.py:116-120)."""
-        if precision not in ("f32", "f16"):
-            raise ValueError(f"precision {precision!r}: 'f32' or 'f16'")
+        # 'f32r' (relaxed fp32): fp32 tensors and accumulation, but the six-term layers keep only their three leading cross terms
+        # (~16 mantissa bits per product; include/crowdmod_hip.h, CM_PRECISION_F32R).  Inside the 1e-4 bound against the
+        # reference, not inside the default plan's 2e-6.  Inference only.
+        if precision not in ("f32", "f16", "f32r"):
+            raise ValueError(f"precision {precision!r}: 'f32', 'f32r' or 'f16'")
         if precision != self.precision:
             self._release()
             self.precision = precision
@@ -146,6 +149,8 @@ class UNet:
         try:
             if self.precision == "f16":
                 native.check(L.cm_model_set_precision(h, native.PRECISION_F16))
+            elif self.precision == "f32r":
+                native.check(L.cm_model_set_precision(h, native.PRECISION_F32R))
             for name, arr in self._params.items():
                 arr = np.ascontiguousarray(arr, dtype=np.float32)
                 native.check(L.cm_model_set_param(h, name.encode(), arr.ctypes.data, arr.size))
