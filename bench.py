@@ -160,7 +160,8 @@ def profile_roofline(model, run, steps, nb, lanes):
     ach = conv3_flops / conv_s / 1e12 if conv_s > 0 else 0.0
     exe = conv3_exec / conv_s / 1e12 if conv_s > 0 else 0.0
     # matrix-pipe roof of THIS instruction mix: the time the issued instructions need at their peaks (fp32 instructions at
-    # 157.3 TF, 16-bit-operand instructions at 2500 TF -- a six-term fp32 product issues six of the latter) over the class time
+    # 157.3 TF, 16-bit-operand instructions at 2500 TF -- an fp32 product of the h2 layers issues three of the latter, of the
+    # six-term layers six) over the class time
     i32, i16 = model.denoiser.conv3_issue_flops(nb)
     pipe_s = steps * (i32 / (FP32_MFMA_PEAK_TFLOPS * 1e12) + i16 / (F16_MFMA_PEAK_TFLOPS * 1e12))
     peak = conv3_exec / pipe_s / 1e12 if pipe_s > 0 else FP32_MFMA_PEAK_TFLOPS
@@ -173,7 +174,8 @@ def profile_roofline(model, run, steps, nb, lanes):
         "frac": exe / peak, "traffic": hbm_traffic(),
         "peak_is": "fp32-equivalent TFLOP/s this launch mix would reach with the matrix pipe never idle: executed fp32-equivalent "
                    "FLOPs / (FLOPs issued as v_mfma_f32_32x32x2_f32 / %.1f TF + FLOPs issued as v_mfma_f32_32x32x16_{bf16,f16} / "
-                   "%.0f TF); six-term layers issue 6 bf16 products per fp32 product, so `frac` = matrix-pipe busy time at peak "
+                   "%.0f TF); h2 layers (f16 two-way splits) issue 3 f16 products per fp32 product, six-term layers (bf16 three-way "
+                   "splits: raw-input layers, training) 6, so `frac` = matrix-pipe busy time at peak "
                    "rate / measured class time (compare SQ_VALU_MFMA_BUSY_CYCLES in profiles/round3_pmc_summary.csv)"
                    % (FP32_MFMA_PEAK_TFLOPS, F16_MFMA_PEAK_TFLOPS),
         "issued_fp32_gflop_per_step": i32 / 1e9, "issued_16bit_gflop_per_step": i16 / 1e9,
@@ -481,8 +483,10 @@ def main():
                  ("config/ATC_synthetic.yml", (24, 72)): "BASELINE configs[4], one GPU's shard",
                  ("config/ATC.yml", (24, 72)): "BASELINE configs[4] shape"}
         tag = known.get((cfg_name, (res.rows, res.cols)), "not a BASELINE config")
-        opnd = ("fp32 arithmetic (fp32 matrix instructions, and fp32 products built from exact three-way bf16 splits -- six "
-                "v_mfma_f32_32x32x16_bf16 terms, fp32 accumulate -- in the Winograd / quarter-resolution / upsample layers)"
+        opnd = ("fp32 arithmetic (fp32 matrix instructions; fp32 products built from f16 two-way splits -- three "
+                "v_mfma_f32_32x32x16_f16 cross terms, fp32 accumulate, same error against the reference as the six-term form -- in "
+                "the Winograd / quarter-resolution / last-conv layers, whose input is GroupNorm + SiLU output; from exact three-way "
+                "bf16 splits -- six v_mfma_f32_32x32x16_bf16 terms -- in the upsample layers, whose input is raw)"
                 if a.dtype == "f32" else "RELAXED fp32 arithmetic: fp32 tensors and accumulation, three of the six bf16 cross terms per product "
                 "(~16 mantissa bits), opt-in" if a.dtype == "f32r" else "f16 matrix-core operands, fp32 accumulate")
         wl = "%s sampling on the %dx%d grid, %s (%s)" % (cfg_name, res.rows, res.cols, opnd, tag)

@@ -2971,17 +2971,19 @@ int cm_debug_conv_info(const cm_model *m, int32_t index, char *buf, int64_t capa
   const Op &op = m->ops[index];
   if (op.kind != OP_CONV) { snprintf(buf, (size_t)capacity, "other %s", op.label.c_str()); return 0; }
   const cm::ConvArgs &a = op.ca;
-  snprintf(buf, (size_t)capacity, "conv %s %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d", op.label.c_str(), a.ntaps, a.stride, a.par,
+  snprintf(buf, (size_t)capacity, "conv %s %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d", op.label.c_str(), a.ntaps, a.stride, a.par,
            a.C0 + a.C1, a.Co, a.Zo, a.Yo, a.Xo, op.NB, op.MB, a.bz, a.by, a.bx, op.ks,
-           (op.small_n ? 1 : 0) | (op.first_k ? 2 : 0) | (op.stat_act ? 4 : 0) | (op.skip_if_fused ? 8 : 0) | (a.CK == 32 ? 16 : 0));
+           (op.small_n ? 1 : 0) | (op.first_k ? 2 : 0) | (op.stat_act ? 4 : 0) | (op.skip_if_fused ? 8 : 0) | (a.CK == 32 ? 16 : 0),
+           op.out_act ? op.out_act->C : a.Co);       // (last field: channel stride of the output tensor, cm_debug_conv_io's h_out)
   return 0;
 }
 
 // Test hook (tests/test_gpu_six_term_hostile.py): conv op `index` ALONE on the caller's data -- no GroupNorm / SiLU on load, no
 // time-embedding row, no residual, no fused skip conv; the bias stays.  h_in0 / h_in1: host, channels-last
 // [B][Zs][Ys][Xs][C0 / C1] (h_in1 null when the op has one source); h_out: host [B][Zo][Yo][Xo][channel stride of the output
-// tensor].  mode 0: the kernel the plan runs (six-term bf16 products where the plan has them); mode 1: the same layer on fp32
-// matrix instructions (the split fragments withheld).
+// tensor].  mode 0: the six-term bf16 form where the plan has one (raw operands are unbounded: never the h2 form); mode 1: the
+// same layer on fp32 matrix instructions (the split fragments withheld); mode 2: the h2 form where the plan has one (the caller
+// keeps its operands inside the bound the plan guarantees, tests/test_gpu_h2.py).
 int cm_debug_conv_io(cm_model *m, int32_t index, int32_t mode, const float *h_in0, const float *h_in1, float *h_out, int32_t B) {
   if (check_ready(m, B)) return 1;
   if (!h_in0 || !h_out || index < 0 || index >= (int)m->ops.size()) return fail("bad argument");
@@ -3087,7 +3089,9 @@ static int exec_flops_split(const cm_model *m, int32_t B, double flops[8], doubl
   for (const Op &op : m->ops) {
     if (op.kind == OP_ATTN) { flops[op.cls] += 4.0 * op.S * (double)op.S * op.E * B; continue; }
     if (op.kind != OP_CONV || op.skip_if_fused) continue;
-    double mult16 = 0.0;     // 0: fp32 matrix instructions; 1: f16 operands; 6: six-term bf16 products
+    double mult16 = 0.0;     // 0: fp32 matrix instructions; 1: f16 operands; 6: six-term bf16 products; 3: h2 / relaxed (three cross terms)
+    const bool h2l = m->precision == CM_PRECISION_F32 && !m->train;   // (as run_conv: inference-only handles of the default plan)
+    const bool rel = m->precision == CM_PRECISION_F32R;
     const cm::ConvArgs &a = op.ca;
     const double Ci = a.C0 + a.C1;
     double f = op.flops_per_sample;
@@ -3098,7 +3102,7 @@ static int exec_flops_split(const cm_model *m, int32_t B, double flops[8], doubl
     } else if (op.fin) {
       // 64-row x 128-column x 32-deep GEMM per (plane, in-plane tile): rows beyond the halo box and columns beyond 27 x Co are padding
       f = (double)(a.Yo / op.fin_by) * (a.Xo / op.fin_bx) * a.Zo * 64.0 * 128.0 * 32.0 * 2;
-      mult16 = (p16 && op.d_wfin16) ? 1.0 : 6.0;
+      mult16 = (p16 && op.d_wfin16) ? 1.0 : ((h2l && op.d_wfin_h2) || rel) ? 3.0 : 6.0;
     } else if ((op.b6d || op.b6s2) && !p16) {
       const double tiles = (double)(a.Zo / op.b6d_bz) * (a.Yo / op.b6d_by) * (a.Xo / op.b6d_bx);
       f = tiles * 32.0 * op.b6d_nw * op.b6d_mbw * a.Co * (Ci * 27.0 + (op.d_wb6d_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
@@ -3109,7 +3113,7 @@ static int exec_flops_split(const cm_model *m, int32_t B, double flops[8], doubl
         cm::QrArgs q{};
         q.C0 = a.C0; q.C1 = a.C1; q.Co = a.Co; q.Y = a.Yo; q.X = a.Xo; q.groups = GN_GROUPS; q.raw = 1; q.wq6 = op.d_wqr_b6;
         if (op.d_wqr_skip) { q.s2w = op.d_wqr_skip; q.s2C0 = op.skip0->C; q.s2C1 = op.skip1 ? op.skip1->C : 0; }
-        if (op.d_wqr_b6 && cm::conv_qr2_b6_ok(q)) mult16 = 6.0;
+        if (op.d_wqr_b6 && cm::conv_qr2_b6_ok(q)) mult16 = ((h2l && op.d_wqr_h2) || rel) ? 3.0 : 6.0;
       }
       const double rows = 2.0 * (a.Yo * a.Xo > 32 ? 2 : 1) * 32;        // whole 32-row blocks, one or two per plane
       f = rows * a.Co * (Ci * 18.0 + (op.d_wqr_skip ? op.skip0->C + (op.skip1 ? op.skip1->C : 0) : 0)) * 2;
@@ -3120,7 +3124,7 @@ static int exec_flops_split(const cm_model *m, int32_t B, double flops[8], doubl
         f = tiles * ((a.Co + 31) / 32) * 16.0 * 32 * 32 * Ci * 3 * 2;
         if (op.d_s2w) f += tiles * ((a.Co + 31) / 32) * 4.0 * 32 * 32 * (op.skip0->C + (op.skip1 ? op.skip1->C : 0)) * 2;
         if (p16 && op.d_wwino16) mult16 = 1.0;
-        else if (!p16 && op.d_wwino_b6 && cm::conv_wino_b6_ok(bz, by, bx, a.Co, a.Zo)) mult16 = 6.0;   // (the fused 1x1 skip conv stays fp32: counted with the layer, a few % of it)
+        else if (!p16 && op.d_wwino_b6 && cm::conv_wino_b6_ok(bz, by, bx, a.Co, a.Zo)) mult16 = ((h2l && op.d_wwino_h2) || rel) ? 3.0 : 6.0;   // (the fused 1x1 skip conv stays fp32: counted with the layer, a few % of it)
       }
     } else if (a.par && op.ups && (op.d_wups16 || !(op.d_wfrag16 && m->precision == CM_PRECISION_F16))) {
       // whole 32-row blocks per (tile, class); planes tiles that span Z skip one of 2 MBW (row block, z tap) pairs
@@ -3128,7 +3132,7 @@ static int exec_flops_split(const cm_model *m, int32_t B, double flops[8], doubl
       const double pairs = 2.0 * op.ups_mbw - ((op.ups_planes && op.ups_tz == a.Zs) ? 1.0 : 0.0);
       f = tiles * 8.0 * 32.0 * pairs * 4.0 * a.Co * Ci * 2;
       if (p16 && op.d_wups16) mult16 = 1.0;
-      else if (!p16 && op.d_wups_b6) mult16 = 6.0;
+      else if (!p16 && op.d_wups_b6) mult16 = rel ? 3.0 : 6.0;
     } else if (a.par) {
       if (p16 && op.d_wfrag16) mult16 = 1.0;
       f = op.flops_per_sample * 8.0 / 27.0;
