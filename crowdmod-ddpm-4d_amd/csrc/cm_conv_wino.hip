@@ -899,6 +899,18 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
     // output transform: A^T = (1,1,1,0), (0,1,-1,-1) along x in registers, along y through LDS (16-byte accesses)
     f32x16 t0 = acc[0] + acc[1] + acc[2];
     f32x16 t1 = acc[1] - acc[2] - acc[3];
+#ifndef CM_WINO_SKIP_EARLY
+#define CM_WINO_SKIP_EARLY 0   // (measured: no gain -- 31.9 vs 32.8, 70.4 vs 69.7 us per layer, step 1.169 vs 1.166 ms)
+#endif
+    constexpr bool SKIP_EARLY = SKIP && B6 == 3 && CM_WINO_SKIP_EARLY;
+    f32x4 ska[4], skw[4];
+    int svox = 0;
+    if constexpr (SKIP) {
+      const int o = outoff[wave * 32 + r];
+      svox = (o >= 0 ? o : 0) + (int)(b * Vo);
+      // h2 (24 registers lighter than the six-term form): the skip conv's first operand chunk travels under the output transform
+      if constexpr (SKIP_EARLY) wino_skip_load1(a, nt, n2a, n2, 0, svox, lane, ska, skw);
+    }
     if constexpr ((CM_WINO_ABL & 16) != 0) {      // (ablation: no epilogue; one store keeps the accumulators alive)
       if (t0[0] + t1[0] == 12345.f) a.out[0] = t0[1];
       __syncthreads();
@@ -930,14 +942,11 @@ __global__ __launch_bounds__(256 * NBW, 2) void conv_wino_p_kernel(const ConvArg
     }
     if constexpr (B6 == 3) v = v * a.h2_oscale;   // (h2 fragments hold w * 2^k; the skip conv below adds to the unscaled sums)
     if constexpr (SKIP) {
-      // operands requested only now, one 32-channel chunk at a time (requesting them under the output transform, or double
-      // buffering them, was the register peak of the kernel and spilled into the chunk loop)
-      f32x4 sa[4], sw[4];
-      const int o = outoff[wave * 32 + r];
-      const int svox = (o >= 0 ? o : 0) + (int)(b * Vo);
+      // operands one 32-channel chunk at a time (double buffering them was the register peak of the kernel and spilled into the
+      // chunk loop: 37 registers even in the h2 form); h2: the FIRST chunk was requested above the output transform
       for (int c2 = 0; c2 < n2; ++c2) {
-        wino_skip_load1(a, nt, n2a, n2, c2, svox, lane, sa, sw);
-        wino_skip_mfma1(sa, sw, v);
+        if (!(SKIP_EARLY && c2 == 0)) wino_skip_load1(a, nt, n2a, n2, c2, svox, lane, ska, skw);
+        wino_skip_mfma1(ska, skw, v);
       }
     }
     // bias, time-embedding row, residual, channels-last store, GroupNorm statistics (slot format of gn_finalize)

@@ -25,6 +25,11 @@ python bench.py --dtype f16 --config config/ATC_synthetic.yml --batch 32 --cpu-b
 python bench.py --config config/ATC_synthetic.yml --batch 32 --cpu-budget 0 > $OUT/bench_f32_24x72.json 2>> $OUT/bench.err
 python bench.py --config config/HERMES-CR-120.yml --channels 3 --cpu-budget 0 > $OUT/bench_f32_cr120.json 2>> $OUT/bench.err
 python bench.py --batch 2 --cpu-budget 0 > $OUT/bench_b2.json 2>> $OUT/bench.err
+python bench.py --dtype f32r --no-secondary --cpu-budget 0 > $OUT/bench_f32r.json 2>> $OUT/bench.err
+# forward error against the reference's own outputs (tests/golden/fwd.npz): default plan (h2), six-term form (CM_NO_H2), relaxed plan
+{ echo "# default plan (h2 where the input is bounded)"; python tools/experiments/fwd_err.py; echo "# CM_DIAG=1 CM_NO_H2=1 (six-term bf16 everywhere: round 3's arithmetic)"; CM_DIAG=1 CM_NO_H2=1 python tools/experiments/fwd_err.py; echo "# relaxed plan (f32r)"; python tools/experiments/fwd_err.py f32r; } > $OUT/fwd_err.txt 2>/dev/null
+# same-box A/B of the default plan against round 3's arithmetic
+{ bash tools/ab_env.sh "" "CM_NO_H2=1" "" "CM_NO_H2=1"; } > $OUT/ab_h2.txt 2>&1
 python tools/step_timeline.py "$OUT/trace/*/*_kernel_trace.csv" > $OUT/step_timeline.txt 2>&1
 python tools/train_timeline.py "$OUT/trace_train/*/*_kernel_trace.csv" > $OUT/train_step_timeline.txt 2>&1
 tail -1 $OUT/trace.log; ls $OUT/*/*/ | head -20
