@@ -238,8 +238,11 @@ int cm_debug_conv_flags(int32_t flags);
 int cm_debug_conv_count(const cm_model *m, int32_t *count);
 int cm_debug_conv_info(const cm_model *m, int32_t index, char *buf, int64_t capacity);
 /* Test hook: conv op `index` alone on caller data (no GroupNorm / SiLU / time row / residual / fused skip; bias stays).
- * h_in0 / h_in1: host channels-last [B][Zs][Ys][Xs][C0 / C1]; h_out: host [B][Zo][Yo][Xo][C of the output tensor];
- * mode 0 = the plan's kernel, 1 = the same layer on fp32 matrix instructions (six-term fragments withheld). */
+ * h_in0 / h_in1: host channels-last [B][Zs][Ys][Xs][C0 / C1]; h_out: host [B][Zo][Yo][Xo][C of the output tensor -- the last
+ * field of cm_debug_conv_info];
+ * mode 0 = the six-term bf16 form where the plan has one (raw operands are unbounded: never the h2 form), 1 = the same layer on
+ * fp32 matrix instructions (split fragments withheld), 2 = the h2 form (f16 two-way splits) where the plan has one: the caller
+ * keeps |x| inside the bound the plan guarantees for that layer (8000; tests/test_gpu_h2.py). */
 int cm_debug_conv_io(cm_model *m, int32_t index, int32_t mode, const float *h_in0, const float *h_in1, float *h_out, int32_t B);
 int cm_debug_time_conv(cm_model *m, int32_t index, int32_t MB, int32_t bz, int32_t by, int32_t bx,
                        int32_t B, int32_t iters, float *us);
