@@ -52,8 +52,12 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
   // 4.1e-7 of the k-ordered fp32 chain, three terms 4.4e-6; measured: whole-forward error against the reference 2.1e-6, exact-fp32 path 2.3e-6),
   // and 16 channels take 6 x 32 cycles instead of 8 x 64.  The staged box is split once per voxel at the LDS write (three
   // bf16 planes per row), the weights arrive pre-split (pack_ups_b6).
-  constexpr bool F16 = PREC == 1, B6 = PREC == 2 || PREC == 3;   // 3: relaxed plan -- three cross terms on the six-term fragments
-  constexpr int U0 = PREC == 3 ? 3 : 0, NTW = PREC == 3 ? 2 : 3;
+  // PREC = 4 (h2, default plan): f16 two-way splits, three cross terms (cm_kernels.h: cm_split2_f16).  The source of this conv is RAW
+  // (the block output, not a GroupNorm output), so its range is taken from the data: the producer's slot statistics bound every element
+  // of the sample (cm_h2_sample_scale), the staged values are multiplied by that power of two before the split and the accumulators by
+  // its inverse (and by the weight scale's) in the epilogue -- a per-sample block exponent, exact.
+  constexpr bool F16 = PREC == 1, B6 = PREC >= 2, H2 = PREC == 4;   // 3: relaxed plan -- three cross terms on the six-term fragments
+  constexpr int U0 = PREC >= 3 ? 3 : 0, NTW = PREC >= 3 ? 2 : 3;
   constexpr int NTM = B6 ? 3 : 1;                // operand terms
   constexpr int S = B6 ? 52 : (F16 ? 20 : 36);   // LDS row stride in dwords: 32 channels (x 3 bf16 planes) + pad
   constexpr int NST = PREC ? 16 : 32;            // steps per 32-channel chunk
@@ -99,6 +103,8 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
   // accumulators at every join: 2 000 register moves per chunk in the first version of this kernel)
   const int mode = (planes && a.bz == a.Zs) ? 1 + pz : 0;
   const int nch = a.C0 >> 5;
+  float sa = 1.f;                                  // h2: this sample's activation scale (a power of two)
+  if constexpr (H2) sa = cm_h2_sample_scale(a.gp0, a.gc0, a.gns0, a.C0, b, A, tid, 256);
 
   auto body = [&](auto mode_c) {
   constexpr int MODE = decltype(mode_c)::value;
@@ -164,7 +170,8 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
           const f32x4 w = ((hok >> k) & 1u) ? ld[kk] : f32x4{0.f, 0.f, 0.f, 0.f};
           if constexpr (B6) {
             cm_u32x2_t t3[3];
-            cm_split3_bf16<NTW>(w, t3);             // hi / mid / lo planes, exact remainders
+            if constexpr (H2) cm_split2_f16(w * sa, t3);   // f16 hi / mid of x 2^k
+            else cm_split3_bf16<NTW>(w, t3);        // hi / mid / lo planes, exact remainders
             if (h < HV) {
 #pragma unroll
               for (int tm = 0; tm < NTW; ++tm) *reinterpret_cast<cm_u32x2_t *>(A + (size_t)h * S + 16 * tm + 2 * q) = t3[tm];
@@ -209,9 +216,14 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int u = U0; u < 6; ++u)
-              acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[s & 1][TA[u]][j]),
-                                                                   __builtin_bit_cast(bf16x8, bw[s % RD][TB[u]][nb]), acc[j][nb], 0, 0, 0);
+            for (int u = U0; u < 6; ++u) {
+              if constexpr (H2)
+                acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[s & 1][TA[u]][j]),
+                                                                    __builtin_bit_cast(f16x8, bw[s % RD][TB[u]][nb]), acc[j][nb], 0, 0, 0);
+              else
+                acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[s & 1][TA[u]][j]),
+                                                                     __builtin_bit_cast(bf16x8, bw[s % RD][TB[u]][nb]), acc[j][nb], 0, 0, 0);
+            }
         } else if constexpr (F16) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
@@ -249,6 +261,7 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
   }
   float *const outb = a.out + (size_t)b * Vo * a.out_cs;
   const int ns = ntp * 8 * MBW;
+  const float osc = H2 ? a.h2_oscale * (1.0f / sa) : 1.f;    // (both factors powers of two: exact)
 #pragma unroll
   for (int j = 0; j < MBW; ++j) {
     int orow[16];
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(256, OCC) void conv_ups_kernel(const ConvArgs a, co
       const bool nok = nn < a.Co;
       float rs[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) rs[e] = acc[j][nb][e] + bias_pre[nb];
+      for (int e = 0; e < 16; ++e) rs[e] = (H2 ? acc[j][nb][e] * osc : acc[j][nb][e]) + bias_pre[nb];
       if (F16 && (a.h16 & 4)) {
         _Float16 *oh = reinterpret_cast<_Float16 *>(a.out) + (size_t)b * Vo * a.out_cs;
 #pragma unroll
@@ -461,7 +474,8 @@ hipError_t launch_conv_ups(const ConvArgs &a_in, int mbw, int planes, int nbp, h
   hipError_t et = ups_tabs_get(a, mbw, planes, &tb);
   if (et != hipSuccess) return et;
   const int nb = ups_nb(a, mbw, nbp), occ = ups_occ(mbw);   // (a workgroup's NB column blocks sit in one packed n tile)
-  const int prec = a.f16;                          // 0: fp32 matrix instruction, 1: f16 operands, 2: bf16 x 6 split products, 3: three of the six
+  const int prec = a.f16;                          // 0: fp32 matrix instruction, 1: f16 operands, 2: bf16 x 6 split products, 3: three of the six, 4: h2
+  if (prec == 4 && !(a.gp0 && a.gc0 && a.gns0 > 0)) return hipErrorInvalidValue;   // h2 takes the source's range from its slot statistics
   const size_t lds = (size_t)tb.HV * (prec >= 2 ? 52 : (prec == 1 ? 20 : 36)) * sizeof(float);
   const dim3 grid((unsigned)(a.B * tb.ntp), (unsigned)(a.Co / (32 * nb)), 2);
   const int HX = a.bx + 2, HYX = (a.by + 2) * HX;
@@ -478,7 +492,7 @@ hipError_t launch_conv_ups(const ConvArgs &a_in, int mbw, int planes, int nbp, h
     hipLaunchKernelGGL((conv_ups_kernel<M, N, O, H>), grid, dim3(256), lds, st, a, tb.tH, tb.tM, tb.HV, tb.ntp, HX, HYX, planes, nbp); \
     return hipGetLastError();                                                                       \
   }
-#define CM_UPS_OCCS(M, N) CM_UPS_GO(M, N, 2, 0) CM_UPS_GO(M, N, 2, 1) CM_UPS_GO(M, N, 2, 2) CM_UPS_GO(M, N, 2, 3)
+#define CM_UPS_OCCS(M, N) CM_UPS_GO(M, N, 2, 0) CM_UPS_GO(M, N, 2, 1) CM_UPS_GO(M, N, 2, 2) CM_UPS_GO(M, N, 2, 3) CM_UPS_GO(M, N, 2, 4)
   CM_UPS_OCCS(1, 1) CM_UPS_OCCS(2, 1) CM_UPS_OCCS(3, 1) CM_UPS_OCCS(4, 1) CM_UPS_OCCS(5, 1) CM_UPS_OCCS(2, 2)
 #undef CM_UPS_OCCS
 #undef CM_UPS_GO

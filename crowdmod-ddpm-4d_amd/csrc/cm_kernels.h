@@ -232,6 +232,43 @@ __device__ __forceinline__ void cm_gn_rows_from_slots(const ConvArgs &a, int b, 
     rows[Ctot + c] = a.gs_beta[c] - M * sc;
   }
 }
+// h2 on a RAW (not normalised) source tensor: a power of two `s` for sample `b` such that every element satisfies |x| s < 2^14, from
+// the producer's slot statistics of that tensor -- a channel's merged (mean, M2) bounds each of its elements: |x - mean| <= sqrt(M2),
+// so |x| <= max_c (|mean_c| + sqrt(M2_c)) =: m, and s = 2^(13 - floor(log2 m)) puts m s in [2^13, 2^14) (f16 max 65504: four times
+// the headroom the fp32 rounding of the statistics could ever need).  All `nth` threads call it (two barriers inside); `scratch`:
+// >= nth / 64 floats of LDS that nothing else uses until the call returns.  Deterministic per sample (fixed merge order).
+__device__ __forceinline__ float cm_h2_sample_scale(const float *__restrict__ gp, const float *__restrict__ gc, int ns, int C, int b,
+                                                    float *scratch, int tid, int nth) {
+  float bm = 0.f;
+  for (int c = tid; c < C; c += nth) {
+    float N = 0.f, M = 0.f, S2 = 0.f;
+    for (int s8 = 0; s8 < ns; s8 += 8) {
+      float cn[8];
+      cm_f32x2_t q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int sl = s8 + u < ns ? s8 + u : ns - 1;
+        cn[u] = s8 + u < ns ? gc[(size_t)b * ns + sl] : 0.f;
+        q[u] = *reinterpret_cast<const cm_f32x2_t *>(gp + (((size_t)b * ns + sl) * C + c) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cm_chan_combine(N, M, S2, cn[u], q[u][0], q[u][1]);
+    }
+    bm = fmaxf(bm, fabsf(M) + sqrtf(fmaxf(S2, 0.f)));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) bm = fmaxf(bm, __shfl_xor(bm, off));
+  if ((tid & 63) == 0) scratch[tid >> 6] = bm;
+  __syncthreads();
+  float m = scratch[0];
+  for (int w = 1; w < (nth >> 6); ++w) m = fmaxf(m, scratch[w]);
+  __syncthreads();
+  const unsigned e = (__float_as_uint(m) >> 23) & 255u;       // m < 2^(e - 126)
+  int se = 267 - (int)e;                                      // biased exponent of 2^(140 - e): m s < 2^14
+  se = se < 32 ? 32 : (se > 222 ? 222 : se);
+  if (!(m > 0.f) || e == 255u) se = 127;                       // all-zero / non-finite statistics: no scaling
+  return __uint_as_float((unsigned)se << 23);
+}
 __device__ __forceinline__ void cm_gn_rows_from_sums(const ConvArgs &a, int b, int V, float *rows, double *scratch, int tid, int nth) {
   const int Ctot = a.C0 + a.C1, cg = Ctot / a.gs_groups;
   for (int c = tid; c < Ctot; c += nth) {

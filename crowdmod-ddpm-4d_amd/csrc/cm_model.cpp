@@ -133,6 +133,7 @@ struct Op {
   // w * 2^k; h2_oscale = 2^-k.  Inference-only handles (a handle that trains keeps the six-term form: its repack kernels do not
   // maintain these fragments).
   float *d_wfin_h2 = nullptr, *d_wwino_h2 = nullptr, *d_wqr_h2 = nullptr;
+  float *d_wups_h2 = nullptr;   // upsample conv (raw source): h2 with a per-sample scale from the source tensor's slot statistics
   float h2_oscale = 1.f;
   bool b6s2 = false;        // fp32 plan: the stride-2 DownSample conv on the same kernel (tile fields above)
   float *d_wb6d = nullptr, *d_wb6d_skip = nullptr;
@@ -532,7 +533,8 @@ static inline void bf16_split3(float w, uint16_t out[3]) {
 // bf16 x 3 fragments of ONE parity class for the stage-once upsample kernel (cm_conv_ups.hip, PREC = 2): [32-channel column
 // block][32-channel chunk][tap 8][16-channel group m][term hi / mid / lo][lane][8 bf16], lane = 32 hh + (co % 32),
 // ci = chunk * 32 + 16 m + 8 hh + i.  W: [Co][Ci][8] (parity_weights of one class).  Returned as floats holding two bf16 each.
-std::vector<float> pack_ups_b6(const float *W, int Co, int Ci) {
+// h2_scale > 0: the h2 form -- f16 hi / mid of w * h2_scale in the first two term slots (third slot zero)
+std::vector<float> pack_ups_b6(const float *W, int Co, int Ci, float h2_scale = 0.f) {
   const int ncb = Co / 32, nch = Ci / 32;
   std::vector<uint16_t> out((size_t)ncb * nch * 8 * 2 * 3 * 64 * 8, 0);
   for (int cb = 0; cb < ncb; ++cb)
@@ -543,7 +545,8 @@ std::vector<float> pack_ups_b6(const float *W, int Co, int Ci) {
             for (int i = 0; i < 8; ++i) {
               const int co = cb * 32 + (lane & 31), ci = ch * 32 + 16 * mg + 8 * (lane >> 5) + i;
               uint16_t t3[3];
-              bf16_split3(W[((size_t)co * Ci + ci) * 8 + t], t3);
+              if (h2_scale > 0.f) f16_split2(W[((size_t)co * Ci + ci) * 8 + t], h2_scale, t3);
+              else bf16_split3(W[((size_t)co * Ci + ci) * 8 + t], t3);
               for (int tm = 0; tm < 3; ++tm)
                 out[(((((((size_t)cb * nch + ch) * 8 + t) * 2 + mg) * 3 + tm) * 64) + lane) * 8 + i] = t3[tm];
             }
@@ -1066,6 +1069,20 @@ int add_conv(cm_model *m, const ConvSpec &s) {
       wb6.insert(wb6.end(), one.begin(), one.end());
     }
     if (upload(m, wb6, &op.d_wups_b6)) return 1;
+    // default plan: h2 with a per-sample scale taken from the source tensor's slot statistics (cm_conv_ups.hip, PREC = 4) -- the
+    // source is a block output with statistics (every conv_2 / attention output carries them)
+    if (m->precision == CM_PRECISION_F32 && !cm::diag_env("CM_NO_H2") && !cm::diag_env("CM_NO_UPS_H2") && s.s0->part) {
+      const float ws = h2_wscale(wp.data(), wp.size());
+      if (ws > 0.f) {
+        std::vector<float> wh2;
+        for (int p8 = 0; p8 < 8; ++p8) {
+          const std::vector<float> one = pack_ups_b6(wp.data() + p8 * per, (int)w.shape[0], Ci_ref, ws);
+          wh2.insert(wh2.end(), one.begin(), one.end());
+        }
+        if (upload(m, wh2, &op.d_wups_h2)) return 1;
+        op.h2_oscale = 1.f / ws;
+      }
+    }
   }
   if (op.ups && m->precision == CM_PRECISION_F16 && Ci_ref == Ci_pad && Ci_ref % 32 == 0 && !cm::diag_env("CM_NO_UPS_F16")) {
     const std::vector<float> wp = parity_weights(wi, (int)w.shape[0], Ci_ref);
@@ -1883,6 +1900,12 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
     // reduced-precision plan's inference forward)
     if (op.d_wups16 && !m->train_fwd) { ca.wfrag = op.d_wups16; ca.wpar_stride = op.wups16_stride; ca.f16 = 1; }
     else if (op.d_wups_b6 && !(m->train_fwd && cm::diag_env("CM_NO_TRAIN_B6"))) { ca.wfrag = op.d_wups_b6; ca.wpar_stride = op.wups_b6_stride; ca.f16 = relaxed ? 3 : 2; }   // six-term bf16 products (training forward too); relaxed plan: three
+    if (ca.f16 == 2 && h2_live && op.d_wups_h2 && op.in0 && op.in0->part && op.in0->nslots > 0 && !m->astat_all && (!op.dbg_raw || op.dbg_h2)) {
+      // default plan, inference-only handle: h2 with the sample's block exponent from the source tensor's slot statistics
+      const Act *si = op.in0;
+      ca.wfrag = op.d_wups_h2; ca.f16 = 4; ca.h2_oscale = op.h2_oscale;
+      ca.gp0 = si->part + (size_t)b0 * si->nslots * si->C * 2; ca.gc0 = si->cnt + (size_t)b0 * si->nslots; ca.gns0 = si->nslots;
+    }
     ca.bz = op.ups_tz; ca.by = op.ups_ty; ca.bx = op.ups_tx;
     ca.ntz = ca.Zs / ca.bz; ca.nty = ca.Ys / ca.by; ca.ntx = ca.Xs / ca.bx;
     if (op.stat_act) {
@@ -3004,9 +3027,17 @@ int cm_debug_conv_io(cm_model *m, int32_t index, int32_t mode, const float *h_in
   tmp.dbg_h2 = mode == 2;
   if (mode == 1) { tmp.d_wwino_b6 = nullptr; tmp.d_wqr_b6 = nullptr; tmp.d_wups_b6 = nullptr; tmp.b6d = false; tmp.b6s2 = false; }
   const int ns_keep = op.stat_act ? op.stat_act->nslots : 0;
+  const int ns_in_keep = op.in0->nslots;
+  if (mode == 2 && op.ups && op.in0->part) {
+    // the upsample conv's h2 form takes its per-sample scale from the source tensor's slot statistics: those of the caller's data
+    const Act *t = op.in0;
+    CM_HIP(cm::launch_chan_stats(t->d, B, t->V(), t->C, t->nslice, t->part, t->cnt, st));
+    const_cast<Act *>(t)->nslots = t->nslice;
+  }
   const int rc = run_conv(m, tmp, B, st, 0, 0);
   const hipError_t e = hipStreamSynchronize(st);
   if (op.stat_act) op.stat_act->nslots = ns_keep;
+  const_cast<Act *>(op.in0)->nslots = ns_in_keep;
   if (rc) return 1;
   if (e != hipSuccess) return fail("debug conv launch failed: %s", hipGetErrorString(e));
   CM_HIP(hipMemcpy(h_out, op.out_act->d, (size_t)B * Vo * op.out_act->C * sizeof(float), hipMemcpyDeviceToHost));
@@ -3132,7 +3163,7 @@ static int exec_flops_split(const cm_model *m, int32_t B, double flops[8], doubl
       const double pairs = 2.0 * op.ups_mbw - ((op.ups_planes && op.ups_tz == a.Zs) ? 1.0 : 0.0);
       f = tiles * 8.0 * 32.0 * pairs * 4.0 * a.Co * Ci * 2;
       if (p16 && op.d_wups16) mult16 = 1.0;
-      else if (!p16 && op.d_wups_b6) mult16 = rel ? 3.0 : 6.0;
+      else if (!p16 && op.d_wups_b6) mult16 = (rel || (h2l && op.d_wups_h2 && !m->astat_all)) ? 3.0 : 6.0;
     } else if (a.par) {
       if (p16 && op.d_wfrag16) mult16 = 1.0;
       f = op.flops_per_sample * 8.0 / 27.0;

@@ -105,6 +105,59 @@ def test_h2_error_bound_on_bounded_operands(net, label, kind):
         assert float((eh / S).max()) <= 2.0 * float((e6 / S).max()) + 1e-7, (label, kind)
 
 
+@pytest.mark.parametrize("kind", ["unit", "range", "cancel", "huge", "minute", "wide"])
+def test_h2_upsample_conv_takes_its_range_from_the_data(net, kind):
+    """The upsample conv's source is RAW (a block output): its h2 form multiplies the staged values by a per-sample power of two
+    derived from the source tensor's slot statistics (|x| <= |mean| + sqrt(M2) per channel; cm_h2_sample_scale), so ANY magnitude
+    whose statistics are finite is in range -- 1e15-sized and 1e-30-sized tensors included -- and only elements far below their
+    sample's maximum sit on the f16 floor, where they no longer matter to S = sum |x| |w|.  Bound: |e| <= (4 e32 + 2e-7) S.
+    Beyond |x| ~ 1e17 the sum of squares behind M2 overflows fp32 -- as it does for GroupNorm itself -- and the h2 form returns
+    non-finite values (loud, not wrong): second test below."""
+    label = "decoder_blocks.5.upsample.1.weight"
+    idx, g = _find(net, label)
+    zs, ys, xs = g["Zo"] // 2, g["Yo"] // 2, g["Xo"] // 2
+    shape = (B, zs, ys, xs, g["Ci"])
+    rng = np.random.default_rng(zlib.crc32(f"h2ups/{kind}".encode()) & 0xFFFF)
+    sgn = rng.choice([-1.0, 1.0], size=shape)
+    if kind == "huge":
+        x = (sgn * rng.uniform(1e14, 1e15, size=shape)).astype(np.float32)
+    elif kind == "minute":
+        x = (sgn * 10.0 ** rng.uniform(-32, -30, size=shape)).astype(np.float32)
+    elif kind == "wide":
+        x = (sgn * 10.0 ** rng.uniform(-30, 15, size=shape)).astype(np.float32)
+    else:
+        x = _inputs(kind, shape, 11)
+    w = np.asarray(net._params_for_test[label], dtype=np.float32)
+    bias = np.asarray(net._params_for_test[label.replace(".weight", ".bias")], dtype=np.float32)
+    oshape = (B, g["Zo"], g["Yo"], g["Xo"], g["Co"])
+    yh = _run(net, idx, 2, x, oshape)
+    y6 = _run(net, idx, 0, x, oshape)
+    y32 = _run(net, idx, 1, x, oshape)
+    ref, S = _ref64(x, w, bias, True)
+    assert np.isfinite(yh).all() and np.isfinite(ref).all()
+    assert not np.array_equal(yh, y6) or kind == "minute", "mode 2 must run the h2 form"   # (minute: the bias is all that is left in fp32)
+    eh, e6, r32 = float((np.abs(yh - ref) / S).max()), float((np.abs(y6 - ref) / S).max()), float((np.abs(y32 - ref) / S).max())
+    print(f"upsample {kind}: h2 {eh:.3e} six {e6:.3e} fp32 {r32:.3e} of S")
+    assert eh <= 4.0 * r32 + 2e-7, (kind, eh, r32)
+
+
+def test_h2_upsample_conv_is_loud_when_the_statistics_overflow(net):
+    """|x| ~ 1e19: M2 = sum (x - mean)^2 is Inf in fp32, the bound is Inf, no scale exists: every output of that sample is
+    non-finite (the six-term bf16 form of mode 0 still returns finite numbers there -- the one regime it covers and h2 does
+    not; a GroupNorm over such a tensor is Inf / NaN in the reference as well)."""
+    label = "decoder_blocks.5.upsample.1.weight"
+    idx, g = _find(net, label)
+    shape = (B, g["Zo"] // 2, g["Yo"] // 2, g["Xo"] // 2, g["Ci"])
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(shape).astype(np.float32)
+    x[0] *= np.float32(1e19)
+    oshape = (B, g["Zo"], g["Yo"], g["Xo"], g["Co"])
+    yh = _run(net, idx, 2, x, oshape)
+    y6 = _run(net, idx, 0, x, oshape)
+    assert np.isfinite(y6).all()
+    assert not np.isfinite(yh[0]).any() and np.isfinite(yh[1]).all()      # per-sample: the other sample is untouched
+
+
 def test_a_layer_whose_groupnorm_affine_breaks_the_static_bound_keeps_the_six_term_form():
     """gamma x 1000 on one GroupNorm: sqrt(n) max|gamma| exceeds the bound the f16 range allows, so that layer must stay on
     the bf16 six-term form (bf16 has fp32's exponent range) -- the forward stays finite and within tolerance of the CPU oracle
