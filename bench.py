@@ -175,7 +175,7 @@ def profile_roofline(model, run, steps, nb, lanes):
         "peak_is": "fp32-equivalent TFLOP/s this launch mix would reach with the matrix pipe never idle: executed fp32-equivalent "
                    "FLOPs / (FLOPs issued as v_mfma_f32_32x32x2_f32 / %.1f TF + FLOPs issued as v_mfma_f32_32x32x16_{bf16,f16} / "
                    "%.0f TF); h2 layers (f16 two-way splits) issue 3 f16 products per fp32 product, six-term layers (bf16 three-way "
-                   "splits: raw-input layers, training) 6, so `frac` = matrix-pipe busy time at peak "
+                   "splits: training handles) 6, so `frac` = matrix-pipe busy time at peak "
                    "rate / measured class time (compare SQ_VALU_MFMA_BUSY_CYCLES in profiles/round3_pmc_summary.csv)"
                    % (FP32_MFMA_PEAK_TFLOPS, F16_MFMA_PEAK_TFLOPS),
         "issued_fp32_gflop_per_step": i32 / 1e9, "issued_16bit_gflop_per_step": i16 / 1e9,
@@ -484,9 +484,9 @@ def main():
                  ("config/ATC.yml", (24, 72)): "BASELINE configs[4] shape"}
         tag = known.get((cfg_name, (res.rows, res.cols)), "not a BASELINE config")
         opnd = ("fp32 arithmetic (fp32 matrix instructions; fp32 products built from f16 two-way splits -- three "
-                "v_mfma_f32_32x32x16_f16 cross terms, fp32 accumulate, same error against the reference as the six-term form -- in "
-                "the Winograd / quarter-resolution / last-conv layers, whose input is GroupNorm + SiLU output; from exact three-way "
-                "bf16 splits -- six v_mfma_f32_32x32x16_bf16 terms -- in the upsample layers, whose input is raw)"
+                "v_mfma_f32_32x32x16_f16 cross terms, fp32 accumulate, same error against the reference as round 3's six-term bf16 "
+                "form -- in the Winograd / quarter-resolution / last-conv layers, whose input is GroupNorm + SiLU output, and in the "
+                "upsample layers, whose raw input is range-bounded per sample by its slot statistics)"
                 if a.dtype == "f32" else "RELAXED fp32 arithmetic: fp32 tensors and accumulation, three of the six bf16 cross terms per product "
                 "(~16 mantissa bits), opt-in" if a.dtype == "f32r" else "f16 matrix-core operands, fp32 accumulate")
         wl = "%s sampling on the %dx%d grid, %s (%s)" % (cfg_name, res.rows, res.cols, opnd, tag)
