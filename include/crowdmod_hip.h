@@ -80,7 +80,11 @@ int cm_model_param_info(const cm_model *m, int32_t index, const char **name, int
 int cm_model_set_param(cm_model *m, const char *name, const float *h_data, int64_t numel);
 int cm_model_get_param(const cm_model *m, const char *name, float *h_data, int64_t numel);
 /* Matrix-core operand type of the inference plan, chosen before cm_model_finalize.  CM_PRECISION_F32 (default):
- * exact fp32 everywhere.  CM_PRECISION_F16: the Winograd 3x3x3 layers (every stride-1 3x3x3 conv with an even
+ * fp32 arithmetic everywhere -- fp32 tensors and accumulation; products on fp32 matrix instructions or, in the 3x3x3 layers that
+ * carry most of the FLOPs, formed from exact-remainder splits of both operands on the 16-bit matrix instructions (f16 two-way
+ * splits / three cross terms where the operand range is bounded, bf16 three-way splits / six cross terms otherwise and on
+ * handles that train): the measured error against the reference is that of an fp32 chain (rms 4e-7).
+ * CM_PRECISION_F16: the Winograd 3x3x3 layers (every stride-1 3x3x3 conv with an even
  * in-plane grid: 71-98 % of the FLOPs) contract f16 operands with fp32 accumulation (v_mfma_f32_32x32x16_f16);
  * GroupNorm statistics, SiLU, residuals, attention and the sampler update stay fp32.  The reference's analogue is
  * torch.amp.autocast around the denoiser (models/diffusion/ddpm.py:116-120).  Tolerance: tests/test_gpu_f16.py.
