@@ -646,3 +646,18 @@ def test_bench_secondary_object_has_one_record_per_other_baseline_config(monkeyp
         assert r["ms_per_step"] > 0 and r["value"] > 0 and r["dtype"] in ("f32", "f16") and r["workload"] and 0 < r["roofline"]["frac"] <= 1
     assert "boom" in sec["configs[0]"]["error"]
     json.dumps(sec)
+
+
+def test_h2_split_simulation_matches_the_six_term_form():
+    """tools/sim_six_term.py, the numpy model behind DESIGN section 4: fp32 products from f16 TWO-way splits (three cross terms,
+    weights packed as w * 2^13) are as close to fp64 as the six-term bf16 form on a Winograd layer's operand distribution, and
+    three bf16 terms (the opt-in relaxed plan) are several times further away."""
+    import importlib.util
+    import os
+    spec_ = importlib.util.spec_from_file_location("sim_six_term", os.path.join(os.path.dirname(__file__), "..", "tools", "sim_six_term.py"))
+    sim = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(sim)
+    out = sim.h2_vs_six(K=288, N=512, seed=3)
+    six, h2, h2s, three, f32 = (out[k][0] for k in ("six-term bf16", "h2 (f16 x 2, 3 terms)", "h2, weights x 2^13", "three-term bf16", "fp32 chain"))
+    assert h2 <= 1.15 * six and h2s <= 1.15 * six, (h2, h2s, six)
+    assert six <= 4.0 * f32 and three >= 2.5 * six, (six, f32, three)
