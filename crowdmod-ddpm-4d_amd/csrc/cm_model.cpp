@@ -124,6 +124,7 @@ struct Op {
   float *d_wups_b6 = nullptr;   // fp32 plan, inference forward: bf16 x 3 split fragments (pack_ups_b6) for the six-term products
   long long wups_b6_stride = 0;
   float *d_w16d = nullptr, *d_w16d_skip = nullptr;
+  bool h2_off = false;      // refresh_h2: this layer's GroupNorm affine no longer satisfies the static bound -> six-term form
   bool dbg_h2 = false;      // cm_debug_conv_io mode 2: raw sources, but the h2 form where the plan has one (the caller bounds its operands)
   bool dbg_raw = false;     // cm_debug_conv_io: the whole-sample quarter-resolution kernel without its GroupNorm (raw sources)
   bool b6d = false;         // fp32 plan: direct six-term kernel (cm_conv_b6d.hip) instead of the six-term Winograd one (inference forward)
@@ -226,6 +227,10 @@ struct cm_model {
   struct cm_train_state *train = nullptr;
   float *dropmask = nullptr;    // [B][nproj] Dropout3d keep-mask/(1-p) of the current training forward
   bool train_fwd = false;
+  // h2 fragments are built from the weights at load time; an optimizer step leaves them behind (the device repack kernels maintain
+  // the bf16 fragments only).  Stale => the inference forward runs the six-term form; the next inference entry point re-derives them
+  // from the master weights (refresh_h2, cm_train_host.inc) -- once per train -> sample transition.
+  bool h2_stale = false;
   // run_ops -> run_conv / fused attention: the GroupNorm finalisation op that follows a K-split layer and can ride in
   // its second pass (cm::launch_combine_gn); `fin_done` reports that it did
   // (the hand-off itself lives in thread-local variables, tl_fin_*: batch lanes enqueue from their own host threads)
@@ -263,6 +268,7 @@ struct cm_model {
 };
 
 namespace {
+int refresh_h2(cm_model *m);   // cm_train_host.inc: h2 fragments from the master weights of a handle that has trained
 
 // ------------------------------------------------------------------------------
 // construction
@@ -948,8 +954,11 @@ static float h2_wscale(const float *w, size_t n) {
   (void)std::frexp(mx, &e);                        // mx = f * 2^e, f in [0.5, 1)
   return std::ldexp(1.0f, 13 - e);                 // mx * 2^(13 - e) in [4096, 8192)
 }
+static bool h2_bound_ok(const std::vector<float> &g, const std::vector<float> &b, const Op &gop, double gain);
 static bool h2_act_bounded(const cm_model *m, const Op &gop, double gain) {
-  const std::vector<float> &g = P(m, gop.gname).host, &b = P(m, gop.bename).host;
+  return h2_bound_ok(P(m, gop.gname).host, P(m, gop.bename).host, gop, gain);
+}
+static bool h2_bound_ok(const std::vector<float> &g, const std::vector<float> &b, const Op &gop, double gain) {
   double gm = 0, bm = 0;
   for (float v : g) gm = std::max(gm, (double)std::fabs(v));
   for (float v : b) bm = std::max(bm, (double)std::fabs(v));
@@ -957,6 +966,36 @@ static bool h2_act_bounded(const cm_model *m, const Op &gop, double gain) {
   const double n = (double)(Ct / GN_GROUPS) * gop.g0->V();
   const double bound = (std::sqrt(n) * gm + bm) * gain;
   return std::isfinite(bound) && bound <= 32000.0;
+}
+
+// h2 fragments of one layer from its weights in the REFERENCE layout (load time: add_conv; after training: refresh_h2).  Return the
+// weight scale 2^k (0: none -- all-zero or non-finite weights).
+static float h2_pack_wino(const float *w_ref, int Co, int Ci_ref, int Ci_pad, std::vector<float> *out) {
+  const std::vector<float> wi = to_internal_taps(w_ref, Co, Ci_ref, 27);
+  std::vector<float> ww;
+  pack_wino(&wi, nullptr, Co, Ci_ref, Ci_pad, &ww, nullptr, nullptr);
+  const float ws = h2_wscale(ww.data(), ww.size());
+  if (ws > 0.f) *out = pack_wino_b6(ww, ws);
+  return ws;
+}
+static float h2_pack_qr(const float *w_ref, int Co, int Ci_ref, std::vector<float> *out) {
+  const std::vector<float> wq = pack_qr(to_internal_taps(w_ref, Co, Ci_ref, 27), Co, Ci_ref);
+  const float ws = h2_wscale(wq.data(), wq.size());
+  if (ws > 0.f) *out = pack_qr_b6(wq, Co, Ci_ref, ws);
+  return ws;
+}
+static float h2_pack_ups(const float *w_ref, int Co, int Ci_ref, std::vector<float> *out) {
+  const std::vector<float> wp = parity_weights(to_internal_taps(w_ref, Co, Ci_ref, 27), Co, Ci_ref);
+  const size_t per = (size_t)Co * Ci_ref * 8;
+  const float ws = h2_wscale(wp.data(), wp.size());
+  if (ws > 0.f) {
+    out->clear();
+    for (int p8 = 0; p8 < 8; ++p8) {
+      const std::vector<float> one = pack_ups_b6(wp.data() + p8 * per, Co, Ci_ref, ws);
+      out->insert(out->end(), one.begin(), one.end());
+    }
+  }
+  return ws;
 }
 
 // Which Winograd-eligible layers take the direct six-term kernel instead.  Round 4, same-box A/B on the full-resolution layers
@@ -1072,13 +1111,9 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     // default plan: h2 with a per-sample scale taken from the source tensor's slot statistics (cm_conv_ups.hip, PREC = 4) -- the
     // source is a block output with statistics (every conv_2 / attention output carries them)
     if (m->precision == CM_PRECISION_F32 && !cm::diag_env("CM_NO_H2") && !cm::diag_env("CM_NO_UPS_H2") && s.s0->part) {
-      const float ws = h2_wscale(wp.data(), wp.size());
+      std::vector<float> wh2;
+      const float ws = h2_pack_ups(w.host.data(), (int)w.shape[0], Ci_ref, &wh2);
       if (ws > 0.f) {
-        std::vector<float> wh2;
-        for (int p8 = 0; p8 < 8; ++p8) {
-          const std::vector<float> one = pack_ups_b6(wp.data() + p8 * per, (int)w.shape[0], Ci_ref, ws);
-          wh2.insert(wh2.end(), one.begin(), one.end());
-        }
         if (upload(m, wh2, &op.d_wups_h2)) return 1;
         op.h2_oscale = 1.f / ws;
       }
@@ -1215,11 +1250,10 @@ int add_conv(cm_model *m, const ConvSpec &s) {
     }
   }
   if (op.wino && op.d_wwino_b6 && h2_plan && h2_act_bounded(m, m->ops[op.gn_op], 4.0)) {
-    std::vector<float> ww;
-    pack_wino(&wi, nullptr, s.Co, Ci_ref, Ci_pad, &ww, nullptr, nullptr);
-    const float ws = h2_wscale(ww.data(), ww.size());
+    std::vector<float> wh2;
+    const float ws = h2_pack_wino(w.host.data(), s.Co, Ci_ref, Ci_pad, &wh2);
     if (ws > 0.f) {
-      if (upload(m, pack_wino_b6(ww, ws), &op.d_wwino_h2)) return 1;
+      if (upload(m, wh2, &op.d_wwino_h2)) return 1;
       op.h2_oscale = 1.f / ws;
     }
   }
@@ -1286,9 +1320,10 @@ int add_conv(cm_model *m, const ConvSpec &s) {
         if (m->precision != CM_PRECISION_F16 && Ci_ref % 64 == 0 && !cm::diag_env("CM_NO_QR_B6") && upload(m, pack_qr_b6(wq, s.Co, Ci_ref), &op.d_wqr_b6))
           return 1;
         if (op.d_wqr_b6 && h2_plan && h2_act_bounded(m, m->ops[op.gn_op], 1.0)) {
-          const float ws = h2_wscale(wq.data(), wq.size());
+          std::vector<float> wh2;
+          const float ws = h2_pack_qr(w.host.data(), s.Co, Ci_ref, &wh2);
           if (ws > 0.f) {
-            if (upload(m, pack_qr_b6(wq, s.Co, Ci_ref, ws), &op.d_wqr_h2)) return 1;
+            if (upload(m, wh2, &op.d_wqr_h2)) return 1;
             op.h2_oscale = 1.f / ws;
           }
         }
@@ -1680,7 +1715,7 @@ int run_conv_qr(cm_model *m, Op &op, int B, hipStream_t st, int b0) {
   q.wq6 = op.d_wqr_b6;
   q.three = (m->precision == CM_PRECISION_F32R && !m->train_fwd) ? 1 : 0;
   // default plan, inference-only handle: the f16 two-way-split form (bounded input: GroupNorm + SiLU inside the kernel)
-  if (m->precision == CM_PRECISION_F32 && !m->train_fwd && !m->train && op.d_wqr_h2 && (!op.dbg_raw || op.dbg_h2)) {
+  if (m->precision == CM_PRECISION_F32 && !m->train_fwd && !m->h2_stale && !op.h2_off && op.d_wqr_h2 && (!op.dbg_raw || op.dbg_h2)) {
     q.wq6 = op.d_wqr_h2; q.three = 2; q.h2_oscale = op.h2_oscale;
   }
   q.temb = ca.temb; q.temb_stride = ca.temb_stride; q.tidx = ca.tidx + b0;
@@ -1806,7 +1841,7 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   // relaxed fp32 plan (cm_model_set_precision): the six-term kernels issue only their three leading cross terms (inference forward)
   const bool relaxed = m->precision == CM_PRECISION_F32R && !m->train_fwd;
   // default plan: the f16 two-way-split form on layers with bounded input (inference-only handles, see Op::d_wfin_h2)
-  const bool h2_live = m->precision == CM_PRECISION_F32 && !m->train_fwd && !m->train;
+  const bool h2_live = m->precision == CM_PRECISION_F32 && !m->train_fwd && !m->h2_stale && !op.h2_off;
   cm::ConvArgs s2a = ca;
   s2a.bz = op.b6d_bz; s2a.by = op.b6d_by; s2a.bx = op.b6d_bx;
   // (the training forward as well: exact splits, fp32 accumulate; its fragments follow every optimizer step)
@@ -2440,6 +2475,7 @@ int cm_model_finalize(cm_model *m) {
 int cm_unet_forward(cm_model *m, const float *d_future, const int64_t *d_t, const float *d_past, float *d_out,
                     int32_t B, void *stream) {
   if (check_ready(m, B)) return 1;
+  if (m->h2_stale && refresh_h2(m)) return 1;
   if (!d_future || !d_t || !d_past || !d_out) return fail("null tensor argument");
   DevGuard g(m->device);
   hipStream_t st = stream ? (hipStream_t)stream : m->stream;
@@ -2637,6 +2673,7 @@ int cm_sample_num_steps(const cm_schedule *s, const cm_sample_opts *opts, int32_
 int cm_sample_loop(cm_model *m, const cm_schedule *s, const float *d_past, const float *d_xT, const float *d_noise,
                    const cm_sample_opts *opts, float *d_out, float *d_history, int32_t B, void *stream) {
   if (check_ready(m, B)) return 1;
+  if (m->h2_stale && refresh_h2(m)) return 1;
   if (!s || !d_past || !opts || !d_out) return fail("null argument");
   if (s->T > TIME_ROWS) return fail("timesteps %d exceed the %d-row time-embedding table (embeddings.py:7)", s->T, TIME_ROWS);
   if (opts->sampler == CM_SAMPLER_FM_EULER && (opts->fm_steps < 1 || opts->fm_time_max_pos < 1 || opts->fm_time_max_pos > TIME_ROWS))
@@ -3121,7 +3158,7 @@ static int exec_flops_split(const cm_model *m, int32_t B, double flops[8], doubl
     if (op.kind == OP_ATTN) { flops[op.cls] += 4.0 * op.S * (double)op.S * op.E * B; continue; }
     if (op.kind != OP_CONV || op.skip_if_fused) continue;
     double mult16 = 0.0;     // 0: fp32 matrix instructions; 1: f16 operands; 6: six-term bf16 products; 3: h2 / relaxed (three cross terms)
-    const bool h2l = m->precision == CM_PRECISION_F32 && !m->train;   // (as run_conv: inference-only handles of the default plan)
+    const bool h2l = m->precision == CM_PRECISION_F32 && !m->h2_stale && !op.h2_off;   // (as run_conv)
     const bool rel = m->precision == CM_PRECISION_F32R;
     const cm::ConvArgs &a = op.ca;
     const double Ci = a.C0 + a.C1;

@@ -82,8 +82,8 @@ int cm_model_get_param(const cm_model *m, const char *name, float *h_data, int64
 /* Matrix-core operand type of the inference plan, chosen before cm_model_finalize.  CM_PRECISION_F32 (default):
  * fp32 arithmetic everywhere -- fp32 tensors and accumulation; products on fp32 matrix instructions or, in the 3x3x3 layers that
  * carry most of the FLOPs, formed from exact-remainder splits of both operands on the 16-bit matrix instructions (f16 two-way
- * splits / three cross terms where the operand range is bounded, bf16 three-way splits / six cross terms otherwise and on
- * handles that train): the measured error against the reference is that of an fp32 chain (rms 4e-7).
+ * splits / three cross terms where the operand range is bounded, bf16 three-way splits / six cross terms otherwise and in the
+ * training step): the measured error against the reference is that of an fp32 chain (rms 4e-7).
  * CM_PRECISION_F16: the Winograd 3x3x3 layers (every stride-1 3x3x3 conv with an even
  * in-plane grid: 71-98 % of the FLOPs) contract f16 operands with fp32 accumulation (v_mfma_f32_32x32x16_f16);
  * GroupNorm statistics, SiLU, residuals, attention and the sampler update stay fp32.  The reference's analogue is
