@@ -28,6 +28,9 @@ namespace cm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef CM_QR2_ABL
+#define CM_QR2_ABL 0         // compile-time ablations of conv_qr2_kernel's split forms (experiments only; results are wrong): 1 one matrix
+#endif                       // instruction per product, 2 no weight refill, 4 no activation, 8 no reduction / epilogue, 16 no GroupNorm merge
 typedef __bf16 bf16x8q __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8q __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4q __attribute__((ext_vector_type(4)));
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
   // ---- this wave's GroupNorm group: per-channel merge of the producers' slots (lane = channel of the group) ----------
   const int c0w = wave * cw;
   const bool norm = a.gamma != nullptr;            // false: the source enters as it is (data gradients of the training step)
-  if (norm) {
+  if (norm && !(CM_QR2_ABL & 16)) {
     float M = 0.f, S2 = 0.f;
     if (lane < cw) {
       const int c = c0w + lane;
@@ -368,9 +371,17 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
       int Cx, cc, ns;
       if (c < a.C0) { p = a.part0; nn = a.cnt0; Cx = a.C0; cc = c; ns = a.ns0; } else { p = a.part1; nn = a.cnt1; Cx = a.C1; cc = c - a.C0; ns = a.ns1; }
       float N = 0.f;
-      for (int s = 0; s < ns; ++s) {
-        const float2 q = *reinterpret_cast<const float2 *>(p + (((size_t)b * ns + s) * Cx + cc) * 2);
-        chan_combine_q(N, M, S2, nn[(size_t)b * ns + s], q.x, q.y);
+      for (int s4 = 0; s4 < ns; s4 += 4) {          // four slots per round trip (the loop paid one per slot: 2-4 slots here)
+        float2 q[4];
+        float cn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int sl = s4 + u < ns ? s4 + u : ns - 1;
+          q[u] = *reinterpret_cast<const float2 *>(p + (((size_t)b * ns + sl) * Cx + cc) * 2);
+          cn[u] = s4 + u < ns ? nn[(size_t)b * ns + sl] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) chan_combine_q(N, M, S2, cn[u], q[u].x, q[u].y);
       }
       gst[wave * 64 + lane] = M;
       gst[wave * 64 + 32 + lane] = S2;
@@ -379,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
   __syncthreads();                                // hvinfo (all waves) and the wave's own gst rows
   // every lane merges the group's channels in channel order (same chain on all lanes: no cross-lane traffic)
   float gmean = 0.f, grstd = 1.f;
-  if (norm) {
+  if (norm && !(CM_QR2_ABL & 16)) {
     float N = 0.f, M = 0.f, S2 = 0.f;
     for (int i = 0; i < cw; ++i) chan_combine_q(N, M, S2, (float)V, gst[wave * 64 + i], gst[wave * 64 + 32 + i]);
     gmean = M;
@@ -424,8 +435,8 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
       if (k < nit) {
         const int it = lane + 64 * k, hv = it >> QSH;
         f32x4 w = ld[k];
-        if (norm) w = w * sc + sh;
-        if (a.silu) { w[0] = silu_q(w[0]); w[1] = silu_q(w[1]); w[2] = silu_q(w[2]); w[3] = silu_q(w[3]); }
+        if (norm && !(CM_QR2_ABL & 4)) w = w * sc + sh;
+        if (a.silu && !(CM_QR2_ABL & 4)) { w[0] = silu_q(w[0]); w[1] = silu_q(w[1]); w[2] = silu_q(w[2]); w[3] = silu_q(w[3]); }
         if (a.pm) w = w * ldp;
         if (ioff[k] < 0 || !cq_ok) w = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (B6) {
@@ -465,7 +476,9 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
 #ifndef CM_QR2_RD
 #define CM_QR2_RD 1
 #endif
-    constexpr int RD = MBP == 1 ? CM_QR2_RD : 1;    // (must divide 9: a slot is tap % RD in every step; 3 is 108 registers)
+    // (must divide 9: a slot is tap % RD in every step.  Six terms: 3 taps would be 108 registers and spill.  h2 loads two of the
+    //  three term slots -- 72 registers, 213 in all -- and three taps of read-ahead are worth 9 of the ten launches' 197 us)
+    constexpr int RD = MBP == 1 ? (B6 == 3 ? 3 : CM_QR2_RD) : 1;
     f32x4 bw[RD][3][3];
 #pragma unroll
     for (int t = 0; t < RD; ++t)
@@ -505,7 +518,7 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
         constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
         auto six = [&](f32x16 &d, const f32x4 (&av)[3], const f32x4 (&wv)[3]) {
 #pragma unroll
-          for (int u = (B6 >= 2 ? 3 : 0); u < 6; ++u) {
+          for (int u = (B6 >= 2 ? 3 : 0); u < ((CM_QR2_ABL & 1) ? (B6 >= 2 ? 4 : 1) : 6); ++u) {
             if constexpr (B6 == 3)
               d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8q, av[TA[u]]), __builtin_bit_cast(f16x8q, wv[TB[u]]), d, 0, 0, 0);
             else
@@ -519,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
           six(acc[j], a1[t9 & 1][j], bw[t9 % RD][2]);
           six(acc[MBP + j], a1[t9 & 1][j], bw[t9 % RD][1]);
         }
-        if (gl + RD < ngw) {
+        if (gl + RD < ngw && !(CM_QR2_ABL & 2)) {
 #pragma unroll
           for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
@@ -621,6 +634,13 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
     }
   }
   // ---- sum the 8 waves' partial accumulators in wave order through LDS (as v1) ----------------------------------------
+  if ((CM_QR2_ABL & 8) != 0) {                      // (ablation: no reduction / epilogue; one store keeps the accumulators alive)
+    float sg = 0.f;
+#pragma unroll
+    for (int i = 0; i < MB; ++i) sg += acc[i][0] + acc[i][9];
+    if (sg == 123.456f) a.out[0] = sg;
+    return;
+  }
   __syncthreads();
   f32x4 *P = reinterpret_cast<f32x4 *>(slices);
 #pragma unroll
