@@ -388,14 +388,7 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
     }
   }
   __syncthreads();                                // hvinfo (all waves) and the wave's own gst rows
-  // every lane merges the group's channels in channel order (same chain on all lanes: no cross-lane traffic)
-  float gmean = 0.f, grstd = 1.f;
-  if (norm && !(CM_QR2_ABL & 16)) {
-    float N = 0.f, M = 0.f, S2 = 0.f;
-    for (int i = 0; i < cw; ++i) chan_combine_q(N, M, S2, (float)V, gst[wave * 64 + i], gst[wave * 64 + 32 + i]);
-    gmean = M;
-    grstd = rsqrtf(S2 / N + a.eps);
-  }
+  float gmean = 0.f, grstd = 1.f;                   // this wave's group statistics (merged below, under the first halo loads)
   // ---- staging items of a step: (halo voxel, channel quad of the step's 8 channels); item = lane + 64 k --------------------
   constexpr int NIT = B6 ? 9 : 6;                  // items per lane: 2 HV / 64 <= 6 (HV <= 192: conv_qr2_ok); B6: 4 HV / 64 <= 9
   constexpr int QSH = B6 ? 2 : 1;                  // log2 channel quads per step
@@ -454,6 +447,14 @@ __global__ __launch_bounds__(512, 2) void conv_qr2_kernel(const QrArgs a) {
       }
   };
   issue(0);
+  // every lane merges the group's channels in channel order (same chain on all lanes: no cross-lane traffic) -- AFTER the halo
+  // loads of the first step have been requested: the 16-channel chain runs under their round trip
+  if (norm && !(CM_QR2_ABL & 16)) {
+    float N = 0.f, M = 0.f, S2 = 0.f;
+    for (int i = 0; i < cw; ++i) chan_combine_q(N, M, S2, (float)V, gst[wave * 64 + i], gst[wave * 64 + 32 + i]);
+    gmean = M;
+    grstd = rsqrtf(S2 / N + a.eps);
+  }
   const int n = nt * 32 + r;
   const float bias_pre = a.bias[n];
   const float tv_pre = a.temb ? a.temb[(size_t)a.tidx[b] * a.temb_stride + n] : 0.f;
