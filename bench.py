@@ -258,6 +258,9 @@ def measure_secondary(a):
         # the headline workload under the opt-in RELAXED fp32 plan (fp32 tensors / accumulation, three of the six bf16 cross terms
         # per product: ~16 mantissa bits; inside north_star's 1e-4 bound, tests/test_gpu_relaxed.py) -- never the headline value
         ("configs[1] under the relaxed fp32 plan (precision 'f32r': ATC 12x36, B=64, C=4)", "config/ATC.yml", None, 4, 64, "f32r"),
+        # ... and under the STRICT fp32 plan (precision 'f32x' = round 3's arithmetic: exact three-way bf16 splits, six cross terms in
+        # every split layer; the same-process reference point of the default plan's f16 two-way-split form)
+        ("configs[1] under the strict fp32 plan (precision 'f32x', six-term bf16 everywhere: ATC 12x36, B=64, C=4)", "config/ATC.yml", None, 4, 64, "f32x"),
     ]
     for wl, path, grid, ch, B, dt in specs:
         t0 = time.perf_counter()
@@ -267,7 +270,7 @@ def measure_secondary(a):
             r["wall_s"] = time.perf_counter() - t0
         except Exception as e:                                    # a secondary record must never take the headline down
             r = {"workload": wl, "error": "%s: %s" % (type(e).__name__, e)}
-        out[wl.split(" ")[0] + ("_f32" if "fp32 arithmetic" in wl else "_f32r" if dt == "f32r" else "")] = r
+        out[wl.split(" ")[0] + ("_f32" if "fp32 arithmetic" in wl else "_" + dt if dt in ("f32r", "f32x") else "")] = r
     t0 = time.perf_counter()
     try:
         ta = argparse.Namespace(batch=128, warmup=3, steps=K, repeats=3)
@@ -372,8 +375,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="chains per GPU (default 64; 128 windows in --mode train)")
     ap.add_argument("--channels", type=int, default=4)
     ap.add_argument("--mode", choices=("sample", "train"), default="sample")
-    ap.add_argument("--dtype", choices=("f32", "f16", "f32r"), default="f32",
-                    help="f32: fp32 arithmetic (default); f16: f16 matrix-core operands in the 3x3x3 convs; f32r: relaxed fp32 (three of the six bf16 cross terms)")
+    ap.add_argument("--dtype", choices=("f32", "f16", "f32r", "f32x"), default="f32",
+                    help="f32: fp32 arithmetic (default); f16: f16 matrix-core operands in the 3x3x3 convs; f32r: relaxed fp32 (three of the six bf16 cross terms); f32x: strict fp32 (six bf16 cross terms everywhere, round 3's arithmetic)")
     ap.add_argument("--grid", type=str, default=None, help="HxW instead of the config's grid (e.g. 24x72)")
     ap.add_argument("--config", type=str, default=None, help="YAML instead of config/ATC.yml (e.g. config/HERMES-CR-120.yml = "
                     "BASELINE configs[3]'s per-GPU shard; its own JSON line)")
@@ -487,7 +490,8 @@ def main():
                 "v_mfma_f32_32x32x16_f16 cross terms, fp32 accumulate, same error against the reference as round 3's six-term bf16 "
                 "form -- in the Winograd / quarter-resolution / last-conv layers, whose input is GroupNorm + SiLU output, and in the "
                 "upsample layers, whose raw input is range-bounded per sample by its slot statistics)"
-                if a.dtype == "f32" else "RELAXED fp32 arithmetic: fp32 tensors and accumulation, three of the six bf16 cross terms per product "
+                if a.dtype == "f32" else "STRICT fp32 arithmetic (round 3's): fp32 products from exact three-way bf16 splits, six "
+                "v_mfma_f32_32x32x16_bf16 cross terms, in every split layer" if a.dtype == "f32x" else "RELAXED fp32 arithmetic: fp32 tensors and accumulation, three of the six bf16 cross terms per product "
                 "(~16 mantissa bits), opt-in" if a.dtype == "f32r" else "f16 matrix-core operands, fp32 accumulate")
         wl = "%s sampling on the %dx%d grid, %s (%s)" % (cfg_name, res.rows, res.cols, opnd, tag)
         out = {

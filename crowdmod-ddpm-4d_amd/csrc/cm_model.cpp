@@ -2437,7 +2437,8 @@ int cm_model_get_param(const cm_model *m, const char *name, float *h_data, int64
 int cm_model_set_precision(cm_model *m, int32_t precision) {
   if (!m) return fail("null model handle");
   if (m->finalized) return fail("precision must be chosen before cm_model_finalize");
-  if (precision != CM_PRECISION_F32 && precision != CM_PRECISION_F16 && precision != CM_PRECISION_F32R) return fail("unknown precision %d", precision);
+  if (precision != CM_PRECISION_F32 && precision != CM_PRECISION_F16 && precision != CM_PRECISION_F32R && precision != CM_PRECISION_F32X)
+    return fail("unknown precision %d", precision);
   m->precision = precision;
   return 0;
 }

@@ -43,7 +43,7 @@ class cm_sample_opts(C.Structure):
 
 
 SAMPLER_DDPM, SAMPLER_DDIM, SAMPLER_FM_EULER = 0, 1, 2
-PRECISION_F32, PRECISION_F16, PRECISION_F32R = 0, 1, 2
+PRECISION_F32, PRECISION_F16, PRECISION_F32R, PRECISION_F32X = 0, 1, 2, 3
 GUIDANCE_NONE, GUIDANCE_SPARSITY = 0, 1
 TABLES = ("beta", "alpha", "alpha_bar", "sqrt_alpha_bar", "one_by_sqrt_alpha", "sqrt_one_minus_alpha_bar")
 

@@ -54,8 +54,10 @@ class UNet:
         # 'f32r' (relaxed fp32): fp32 tensors and accumulation, but the six-term layers keep only their three leading cross terms
         # (~16 mantissa bits per product; include/crowdmod_hip.h, CM_PRECISION_F32R).  Inside the 1e-4 bound against the
         # reference, not inside the default plan's 2e-6.  Inference only.
-        if precision not in ("f32", "f16", "f32r"):
-            raise ValueError(f"precision {precision!r}: 'f32', 'f32r' or 'f16'")
+        # 'f32x' (strict fp32, round 3's arithmetic): the default plan without the f16 two-way-split form -- exact three-way bf16
+        # splits, six cross terms, in every split layer (CM_PRECISION_F32X): same measured error, 16 % slower.
+        if precision not in ("f32", "f16", "f32r", "f32x"):
+            raise ValueError(f"precision {precision!r}: 'f32', 'f32x', 'f32r' or 'f16'")
         if precision != self.precision:
             self._release()
             self.precision = precision
@@ -151,6 +153,8 @@ class UNet:
                 native.check(L.cm_model_set_precision(h, native.PRECISION_F16))
             elif self.precision == "f32r":
                 native.check(L.cm_model_set_precision(h, native.PRECISION_F32R))
+            elif self.precision == "f32x":
+                native.check(L.cm_model_set_precision(h, native.PRECISION_F32X))
             for name, arr in self._params.items():
                 arr = np.ascontiguousarray(arr, dtype=np.float32)
                 native.check(L.cm_model_set_param(h, name.encode(), arr.ctypes.data, arr.size))

@@ -92,8 +92,12 @@ int cm_model_get_param(const cm_model *m, const char *name, float *h_data, int64
  * products are formed from bf16 splits keep only the three leading cross terms of the six (hi x hi, hi x mid, mid x hi: two-way
  * splits, ~16 mantissa bits per product instead of 24) -- the analogue of PyTorch's default conv arithmetic on the reference's own
  * GPUs (torch.backends.cudnn.allow_tf32 = True: 10 mantissa bits), six bits finer.  Inference only; the forward stays inside the
- * 1e-4 max-abs bound against the reference (tests/test_gpu_relaxed.py), not inside the default plan's 2e-6. */
-enum { CM_PRECISION_F32 = 0, CM_PRECISION_F16 = 1, CM_PRECISION_F32R = 2 };
+ * 1e-4 max-abs bound against the reference (tests/test_gpu_relaxed.py), not inside the default plan's 2e-6.
+ * CM_PRECISION_F32X ("strict fp32", round 3's arithmetic): the default plan with the f16 two-way-split form switched off -- every
+ * split layer forms its products from exact three-way bf16 splits, six cross terms (all 24 mantissa bits of both operands, dropped
+ * terms <= 2^-24 of a product, fp32's whole exponent range).  Same measured error as the default plan, 16 % slower; for callers
+ * that want the stronger per-product statement, and the reference point of the A/B in DESIGN.md section 4. */
+enum { CM_PRECISION_F32 = 0, CM_PRECISION_F16 = 1, CM_PRECISION_F32R = 2, CM_PRECISION_F32X = 3 };
 int cm_model_set_precision(cm_model *m, int32_t precision);
 /* Packs weights into MFMA fragment order and precomputes the time-embedding
  * tables; must be called after the last cm_model_set_param and before any

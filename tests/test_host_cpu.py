@@ -637,7 +637,8 @@ def test_bench_secondary_object_has_one_record_per_other_baseline_config(monkeyp
     monkeypatch.setattr(bench, "measure_sampling", fake_sampling)
     monkeypatch.setattr(bench, "measure_train", fake_train)
     sec = bench.measure_secondary(argparse.Namespace(lanes=2))
-    assert set(sec) == {"configs[3]", "configs[4]", "configs[4]_f32", "configs[0]", "configs[2]", "configs[1]_f32r"}
+    assert set(sec) == {"configs[3]", "configs[4]", "configs[4]_f32", "configs[0]", "configs[2]", "configs[1]_f32r", "configs[1]_f32x"}
+    assert ("config/ATC.yml", None, 4, 64, "f32x", 50) in calls and sec["configs[1]_f32x"]["dtype"] == "f32x"
     assert ("config/HERMES-CR-120.yml", None, 3, 64, "f32", 50) in calls
     assert ("config/ATC.yml", None, 4, 64, "f32r", 50) in calls and sec["configs[1]_f32r"]["dtype"] == "f32r"
     assert ("config/ATC_synthetic.yml", (24, 72), 3, 32, "f16", 50) in calls

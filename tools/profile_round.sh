@@ -26,6 +26,7 @@ python bench.py --config config/ATC_synthetic.yml --batch 32 --cpu-budget 0 > $O
 python bench.py --config config/HERMES-CR-120.yml --channels 3 --cpu-budget 0 > $OUT/bench_f32_cr120.json 2>> $OUT/bench.err
 python bench.py --batch 2 --cpu-budget 0 > $OUT/bench_b2.json 2>> $OUT/bench.err
 python bench.py --dtype f32r --no-secondary --cpu-budget 0 > $OUT/bench_f32r.json 2>> $OUT/bench.err
+python bench.py --dtype f32x --no-secondary --cpu-budget 0 > $OUT/bench_f32x.json 2>> $OUT/bench.err
 # forward error against the reference's own outputs (tests/golden/fwd.npz): default plan (h2), six-term form (CM_NO_H2), relaxed plan
 { echo "# default plan (h2 where the input is bounded)"; python tools/experiments/fwd_err.py; echo "# CM_DIAG=1 CM_NO_H2=1 (six-term bf16 everywhere: round 3's arithmetic)"; CM_DIAG=1 CM_NO_H2=1 python tools/experiments/fwd_err.py; echo "# relaxed plan (f32r)"; python tools/experiments/fwd_err.py f32r; } > $OUT/fwd_err.txt 2>/dev/null
 # same-box A/B of the default plan against round 3's arithmetic
