@@ -1082,6 +1082,16 @@ bool conv_wino_two_step(int bz, int by, int bx, bool f16, int nbw) { return (bz 
 
 // output tiles per workgroup: two (512 threads) for layers with a multiple of 64 output channels, except on the 8x2x2 tile
 int conv_wino_nbw(int bz, int Co) { return (bz != 8 && Co % 64 == 0) ? 2 : 1; }
+static int wino_cu_count();
+// ... of ONE launch.  f16 operands (reduced-precision plan): the matrix phase is a sixteenth of the fp32 one and the launch is a latency
+// chain, so two output tiles per workgroup only pay when the two-tile grid still fills the chip -- the quarter resolution of the
+// 24 x 72 grid at B = 32 is 128 two-tile workgroups on 256 CUs: one tile per workgroup, 1.756 -> 1.689 ms per step of that plan
+int conv_wino_nbw_run(const ConvArgs &a, bool f16) {
+  const int nbw = conv_wino_nbw(a.bz, a.Co);
+  static const bool keep = cm::diag_env("CM_WINO_F16_NBW2") != nullptr;
+  if (f16 && nbw == 2 && !keep && (long long)a.B * a.ntz * a.nty * a.ntx * (a.Co / 64) < wino_cu_count()) return 1;
+  return nbw;
+}
 
 size_t conv_wino_lds(int bz, int by, int bx, bool f16, int nbw) {
   const size_t ur = (size_t)(bz + 2) * (by / 2) * (bx / 2);
@@ -1193,7 +1203,7 @@ hipError_t launch_conv_wino(const ConvArgs &a_in, bool f16, hipStream_t st) {
   ConvArgs a = a_in;
   a.dbg = conv_dbg_flags();
   if (!conv_wino_ok(a)) return hipErrorInvalidValue;
-  const int nbw = conv_wino_nbw(a.bz, a.Co);
+  const int nbw = conv_wino_nbw_run(a, f16);
   const bool b6 = a.f16 == 2 || a.f16 == 3 || a.f16 == 4;   // 3: the relaxed plan's three-term form on the same fragments;
   const bool t3 = a.f16 == 3, h2 = a.f16 == 4;               // 4: h2 fragments (f16 hi / mid of w * 2^k), three f16 cross terms
   if (b6 && (f16 || !conv_wino_b6_ok(a.bz, a.by, a.bx, a.Co, a.Zo))) return hipErrorInvalidValue;

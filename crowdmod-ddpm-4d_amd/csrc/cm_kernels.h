@@ -346,6 +346,7 @@ bool conv_wino_tile_ok(int bz, int by, int bx);
 bool conv_wino_ok(const ConvArgs &a);
 size_t conv_wino_lds(int bz, int by, int bx, bool f16, int nbw);
 int conv_wino_nbw(int bz, int Co);
+int conv_wino_nbw_run(const ConvArgs &a, bool f16);   // ... of one launch (a.B, a.ntz / nty / ntx set): see cm_conv_wino.hip
 bool conv_wino_two_step(int bz, int by, int bx, bool f16, int nbw);
 // f16: a.wfrag holds the f16 packing (3 groups per chunk and wave, 8 halves per lane): fp32 accumulate, f16 operands
 hipError_t launch_conv_wino(const ConvArgs &a, bool f16, hipStream_t st);

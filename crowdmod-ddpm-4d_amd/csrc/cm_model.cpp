@@ -1886,7 +1886,7 @@ int run_conv(cm_model *m, Op &op, int B, hipStream_t st, int b0, int slab) {
   if (!m->train_fwd && op.gn_op >= 0 && m->ops[op.gn_op].fin_skipped[slab & 3] && ca.gn) {
     const Op &g = m->ops[op.gn_op];
     const Act *g0 = g.g0, *g1 = g.g1;
-    const int nbw = cm::conv_wino_nbw(ca.bz, ca.Co);
+    const int nbw = cm::conv_wino_nbw_run(ca, wino_f16);
     const bool p_kernel = take_wino && cm::conv_wino_two_step(ca.bz, ca.by, ca.bx, wino_f16, nbw) && (nbw == 2 || wino_b6);
     if (p_kernel) {
       ca.gp0 = g0->part + (size_t)b0 * g0->nslots * g0->C * 2; ca.gc0 = g0->cnt + (size_t)b0 * g0->nslots; ca.gns0 = g0->nslots;
