@@ -1325,6 +1325,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const ConvArgs a, co
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *V = lds;                                  // [16][UR][32]
   float *Yt = V + 16 * UR * 32;                    // [32 rows][32 co][4 = (a, b)]
+  // TWO (full-resolution tile, round 4): two-step staging as in the forward kernel -- every halo voxel of the tile is loaded and
+  // activated ONCE into R[voxel][32 ci (+ 4 pad)], the 4 x 4 patches are then read from LDS: a patch item used to load and activate its
+  // 16 voxels itself, four times per voxel (GroupNorm + SiLU: two quarter-rate transcendentals per element).  The half-resolution
+  // tile's V image (123 KB) leaves no room for R.
+#ifndef CM_WGRAD_TWO
+#define CM_WGRAD_TWO 1
+#endif
+  constexpr bool TWO = BZ == 8 && CM_WGRAD_TWO;
+  constexpr int RYH = 2 * PY + 2, RXH = 2 * PX + 2, RVX = HZ * RYH * RXH, RSX = 36;
+  float *R = Yt + 32 * 32 * 4;                     // [RVX][RSX] (TWO only)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = w8 & 3, xh = w8 >> 2;          // frequency row xi_y, and which two of its four xi_x components
@@ -1354,6 +1364,49 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const ConvArgs a, co
     const int py0 = min(ty * PY, pyt - PY), px0 = min(tx * PX, pxt - PX);
     const int z0 = tz * BZ, y0 = 2 * py0, x0 = 2 * px0;
     __syncthreads();                               // previous tile's operands have been read
+    if constexpr (TWO) {
+      // ---- step A: every halo voxel of the tile, activated once, into R ---------------------------------------------
+      constexpr int RK = (RVX * 8 + 511) / 512;
+      const int quad = tid & 7;
+      const int c = ci0 + 4 * quad;
+      const bool cok = c < Ctot;
+      const bool from0 = c < a.C0;
+      const float *sp = from0 ? a.src0 + c : a.src1 + (c - a.C0);
+      const int Cs = from0 ? a.C0 : a.C1;
+      f32x4 sc1 = {1.f, 1.f, 1.f, 1.f}, sh1 = {0.f, 0.f, 0.f, 0.f}, pm1 = {1.f, 1.f, 1.f, 1.f};
+      const int cc = cok ? c : 0;
+      if (a.gn) {
+        const float *gp = a.gn + (size_t)b * 2 * Ctot + cc;
+        sc1 = *reinterpret_cast<const f32x4 *>(gp);
+        sh1 = *reinterpret_cast<const f32x4 *>(gp + Ctot);
+      }
+      if (a.pm) pm1 = *reinterpret_cast<const f32x4 *>(a.pm + (size_t)b * a.pm_stride + cc);
+      f32x4 ld[RK];
+      unsigned okm = 0;
+#pragma unroll
+      for (int k = 0; k < RK; ++k) {
+        const int v = (tid >> 3) + 64 * k;
+        const int zi = v / (RYH * RXH), rem = v - zi * (RYH * RXH), ry = rem / RXH, rx = rem - ry * RXH;
+        const int cz = z0 - 1 + zi, cyy = y0 - 1 + ry, cxx = x0 - 1 + rx;
+        const bool ok = v < RVX && cok && cz >= 0 && cz < a.Zs && cyy >= 0 && cyy < a.Ys && cxx >= 0 && cxx < a.Xs;
+        const int off = ok ? ((b * a.Zs + cz) * a.Ys + cyy) * a.Xs + cxx : 0;
+        ld[k] = *reinterpret_cast<const f32x4 *>(sp + (size_t)off * Cs);
+        okm |= (ok ? 1u : 0u) << k;
+      }
+#pragma unroll
+      for (int k = 0; k < RK; ++k) {
+        const int v = (tid >> 3) + 64 * k;
+        f32x4 w = ld[k];
+        if (a.gn) {
+          w = w * sc1 + sh1;
+          if (a.silu) { w[0] = silu_w(w[0]); w[1] = silu_w(w[1]); w[2] = silu_w(w[2]); w[3] = silu_w(w[3]); }
+        }
+        if (a.pm) w = w * pm1;
+        if (!((okm >> k) & 1u)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (v < RVX) *reinterpret_cast<f32x4 *>(R + (size_t)v * RSX + 4 * quad) = w;
+      }
+      __syncthreads();
+    }
     // ---- V = B^T d B of the conv's actual input (GroupNorm + SiLU + Dropout3d multiplier as in the forward) ----
     {
       const int it = tid;
@@ -1362,12 +1415,19 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const ConvArgs a, co
       const int quad = itc & 7, patch = (itc >> 3) % NP, zi = itc / (8 * NP);
       const int py = patch / PX, px = patch % PX;
       const int c = ci0 + 4 * quad;                // channel quad in the concatenated channel space
+      f32x4 d[16];
+      if constexpr (TWO) {
+        const float *rb = R + (size_t)((zi * RYH + 2 * py) * RXH + 2 * px) * RSX + 4 * quad;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[i * 4 + j] = *reinterpret_cast<const f32x4 *>(rb + (size_t)(i * RXH + j) * RSX);
+      } else {
       const bool from0 = c < a.C0;
       const float *sp = from0 ? a.src0 + c : a.src1 + (c - a.C0);
       const int Cs = from0 ? a.C0 : a.C1;
       const int cz = z0 - 1 + zi;
       const bool zok = stager && c < Ctot && cz >= 0 && cz < a.Zs;
-      f32x4 d[16];
       unsigned okmask = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -1396,6 +1456,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const ConvArgs a, co
         }
         if (a.pm) w = w * pm1;
         d[k] = ((okmask >> k) & 1u) ? w : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -1523,7 +1584,8 @@ __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float *__r
 }
 
 size_t wgrad_wino_lds(int bz, int by, int bx) {
-  return ((size_t)16 * (bz + 2) * (by / 2) * (bx / 2) * 32 + 32 * 32 * 4) * sizeof(float);
+  const size_t r = (bz == 8 && CM_WGRAD_TWO) ? (size_t)(bz + 2) * (by + 2) * (bx + 2) * 36 : 0;      // the activated halo image of the two-step form
+  return ((size_t)16 * (bz + 2) * (by / 2) * (bx / 2) * 32 + 32 * 32 * 4 + r) * sizeof(float);
 }
 
 hipError_t launch_wgrad_wino(const ConvArgs &a, const float *dy, int dy_cs, float *part, int G, int ncb, int nkb, hipStream_t st) {
